@@ -1,0 +1,378 @@
+"""Host-side driver shared by ``ilqr_amd.ilqr`` and ``ilqr_amd.cilqr``.
+
+Owns the device buffers (PyTorch-ROCm tensors, used only as carriers of device
+memory and of the HIP stream), converts between the reference's array layout
+and the tiled device layout, and calls the C-ABI library.  All numerical work
+happens in the HIP kernels; nothing here computes a cost, a gain or a rollout.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .systems import System
+
+_TORCH = None
+
+
+def _torch():
+    global _TORCH
+    if _TORCH is None:
+        import torch
+        _TORCH = torch
+    return _TORCH
+
+
+def _np_dtype(dtype):
+    dt = np.dtype(dtype)
+    if dt not in (np.dtype(np.float64), np.dtype(np.float32)):
+        raise ValueError("dtype must be float64 or float32")
+    return dt
+
+
+def n_tiles(B):
+    return (int(B) + _lib.TILE - 1) // _lib.TILE
+
+
+class DeviceProblem:
+    """Device-resident state of one batched solve: the tiled trajectory/gain
+    buffers, the per-problem scalars and the library handle."""
+
+    def __init__(self, system, B, N, dtype, device, *, max_iter, lm_parameter, alpha_floor,
+                 constraint_mode=_lib.CONSTR_NONE, input_limit_lambda=1e-4, barrier_mu=0.0,
+                 barrier_delta=0.1, vel_bounds=(0.0, 0.0), lanes_per_problem=0, alphas_per_lane=0,
+                 history=False, solver_limits=False):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _lib.IlqrError("no GPU visible: the batched iLQR solve runs on the HIP device only")
+        if getattr(system, "device_model_id", None) is None:
+            raise _lib.IlqrError(
+                f"{type(system).__name__} has no device dynamics; use Car, CarAcceleration or DubinsCar")
+        self.lib = _lib.lib()
+        self.device = torch.device(device if device is not None else "cuda")
+        self.np_dtype = _np_dtype(dtype)
+        self.t_dtype = torch.float64 if self.np_dtype == np.float64 else torch.float32
+        self.B, self.N = int(B), int(N)
+        self.n, self.m = int(system.state_size), int(system.control_size)
+        self.max_iter = int(max_iter)
+        n, m, N, B = self.n, self.m, self.N, self.B
+
+        d = _lib.Desc()
+        d.B, d.N, d.n, d.m = B, N, n, m
+        d.model = int(system.device_model_id)
+        d.dtype = _lib.F64 if self.np_dtype == np.float64 else _lib.F32
+        d.control_limited = int(bool(system.control_limited))
+        d.constraint_mode = int(constraint_mode)
+        d.n_alphas = 0
+        d.lanes_per_problem, d.alphas_per_lane = int(lanes_per_problem), int(alphas_per_lane)
+        d.dt = float(system.dt)
+        d.lm_parameter = float(lm_parameter)
+        d.alpha_floor = float(alpha_floor)
+        d.input_limit_lambda = float(input_limit_lambda)
+        d.barrier_mu, d.barrier_delta = float(barrier_mu), float(barrier_delta)
+        d.vel_bounds[0], d.vel_bounds[1] = float(vel_bounds[0]), float(vel_bounds[1])
+        Q = np.asarray(system.Q, dtype=np.float64)
+        R = np.asarray(system.R, dtype=np.float64)
+        Qf = np.asarray(system.Q_f, dtype=np.float64)
+        if Q.shape != (n, n) or Qf.shape != (n, n) or R.shape != (m, m):
+            raise ValueError("Q / Q_f must be (n, n) and R (m, m)")
+        for i, v in enumerate(Q.ravel()):
+            d.Q[i] = v
+        for i, v in enumerate(Qf.ravel()):
+            d.Qf[i] = v
+        for i, v in enumerate(R.ravel()):
+            d.R[i] = v
+        if system.control_limited or solver_limits:
+            lo, hi = system.control_lower_limit, system.control_upper_limit
+            for j in range(m):
+                d.lo[j], d.hi[j] = float(lo[j]), float(hi[j])
+        self.desc = d
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.ilqr_create(C.byref(d), C.byref(self.handle)), "ilqr_create")
+        self.n_alphas = int(self.lib.ilqr_num_alphas(self.handle))
+
+        Bp = n_tiles(B) * _lib.TILE
+        dev, td = self.device, self.t_dtype
+        with torch.cuda.device(self.device):
+            self.X = torch.zeros(Bp * N * n, dtype=td, device=dev)
+            self.U = torch.zeros(Bp * (N - 1) * m, dtype=td, device=dev)
+            self.Xref = torch.zeros(Bp * N * n, dtype=td, device=dev)
+            self.K = torch.zeros(Bp * (N - 1) * m * n, dtype=td, device=dev)
+            self.k = torch.zeros(Bp * (N - 1) * m, dtype=td, device=dev)
+            self.J = torch.zeros(B, dtype=td, device=dev)
+            self.converged = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.iters = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.alpha_idx = torch.full((B,), -1, dtype=torch.int32, device=dev)
+            self.status = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.work = torch.zeros(int(self.lib.ilqr_workspace_bytes(self.handle)), dtype=torch.uint8,
+                                    device=dev)
+            self.centers = self.radius = None
+            if constraint_mode & _lib.CONSTR_BARRIER:
+                self.centers = torch.zeros(Bp * N * 2, dtype=td, device=dev)
+                self.radius = torch.ones(Bp * N, dtype=td, device=dev)
+            self.hist_cost = self.hist_alpha = None
+            if history:
+                self.hist_cost = torch.full((self.max_iter, B), float("nan"), dtype=td, device=dev)
+                self.hist_alpha = torch.full((self.max_iter, B), -2, dtype=torch.int32, device=dev)
+        self._bind()
+
+    # -- plumbing ---------------------------------------------------------
+    def _bind(self):
+        b = _lib.Buffers()
+        b.X, b.U, b.Xref = self.X.data_ptr(), self.U.data_ptr(), self.Xref.data_ptr()
+        b.K, b.k, b.J = self.K.data_ptr(), self.k.data_ptr(), self.J.data_ptr()
+        b.converged, b.iters = self.converged.data_ptr(), self.iters.data_ptr()
+        b.alpha_idx, b.status = self.alpha_idx.data_ptr(), self.status.data_ptr()
+        b.work = self.work.data_ptr()
+        if self.centers is not None:
+            b.centers, b.radius = self.centers.data_ptr(), self.radius.data_ptr()
+        if self.hist_cost is not None:
+            b.hist_cost, b.hist_alpha = self.hist_cost.data_ptr(), self.hist_alpha.data_ptr()
+            b.hist_capacity = self.max_iter
+        self.buffers = b
+        _lib.check(self.lib.ilqr_bind(self.handle, C.byref(b)), "ilqr_bind")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.ilqr_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def stream(self):
+        torch = _torch()
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _upload(self, host, tiled, rows):
+        """host: array-like (B, rows...) in the reference layout -> tiled device buffer."""
+        torch = _torch()
+        if isinstance(host, torch.Tensor):
+            src = host.to(device=self.device, dtype=self.t_dtype).reshape(self.B, rows).contiguous()
+        else:
+            a = np.ascontiguousarray(np.asarray(host, dtype=self.np_dtype).reshape(self.B, rows))
+            src = torch.from_numpy(a).to(self.device)
+        _lib.check(self.lib.ilqr_to_tiled(src.data_ptr(), tiled.data_ptr(), self.B, rows,
+                                          self.np_dtype.itemsize, self.stream()), "ilqr_to_tiled")
+        # `src` must outlive the asynchronous kernel: both run on the current stream, and torch's
+        # caching allocator only reuses the block for later work on that same stream.
+
+    def _download(self, tiled, rows, shape):
+        torch = _torch()
+        dst = torch.empty(self.B * rows, dtype=self.t_dtype, device=self.device)
+        _lib.check(self.lib.ilqr_from_tiled(tiled.data_ptr(), dst.data_ptr(), self.B, rows,
+                                            self.np_dtype.itemsize, self.stream()), "ilqr_from_tiled")
+        return dst.cpu().numpy().reshape(shape)
+
+    # -- data movement ------------------------------------------------------
+    def upload(self, target_states, states, inputs, converged=None, centers=None, radius=None):
+        N, n, m = self.N, self.n, self.m
+        self._upload(target_states, self.Xref, N * n)
+        self._upload(states, self.X, N * n)
+        self._upload(inputs, self.U, (N - 1) * m)
+        torch = _torch()
+        if converged is not None:
+            c = np.ascontiguousarray(np.asarray(converged).reshape(self.B).astype(np.int32))
+            self.converged.copy_(torch.from_numpy(c))
+        if self.centers is not None:
+            if centers is None or radius is None:
+                raise ValueError("barrier mode needs centers (B, N, 2) and radius (B, N)")
+            self._upload(centers, self.centers, N * 2)
+            self._upload(radius, self.radius, N)
+
+    def download_states(self):
+        return self._download(self.X, self.N * self.n, (self.B, self.N, self.n))
+
+    def download_inputs(self):
+        return self._download(self.U, (self.N - 1) * self.m, (self.B, self.N - 1, self.m))
+
+    def download_K(self):
+        return self._download(self.K, (self.N - 1) * self.m * self.n, (self.B, self.N - 1, self.m, self.n))
+
+    def download_k(self):
+        return self._download(self.k, (self.N - 1) * self.m, (self.B, self.N - 1, self.m, 1))
+
+    # -- solver phases (asynchronous on the current stream) -----------------
+    def initial_cost(self):
+        _lib.check(self.lib.ilqr_initial_cost(self.handle, self.stream()), "ilqr_initial_cost")
+
+    def backward(self):
+        _lib.check(self.lib.ilqr_backward(self.handle, self.stream()), "ilqr_backward")
+
+    def forward(self, iteration=0):
+        _lib.check(self.lib.ilqr_forward(self.handle, int(iteration), self.stream()), "ilqr_forward")
+
+    def forward_evaluate(self):
+        _lib.check(self.lib.ilqr_forward_evaluate(self.handle, self.stream()), "ilqr_forward_evaluate")
+
+    def forward_commit(self, iteration=0):
+        _lib.check(self.lib.ilqr_forward_commit(self.handle, int(iteration), self.stream()),
+                   "ilqr_forward_commit")
+
+    def solve(self, max_iter=None):
+        mi = self.max_iter if max_iter is None else int(max_iter)
+        _lib.check(self.lib.ilqr_solve(self.handle, mi, self.stream()), "ilqr_solve")
+
+    def active_count(self):
+        out = C.c_int32(0)
+        _lib.check(self.lib.ilqr_active_count(self.handle, self.stream(), C.byref(out)), "ilqr_active_count")
+        return out.value
+
+
+class BatchedSolverBase:
+    """Attribute surface of the reference solver object (``ilqr.py:17-34``) with a
+    leading batch axis.  ``target_states`` may be ``(N, n)`` (one problem, exactly
+    the reference call) or ``(B, N, n)``."""
+
+    _default_max_iter = 30
+    _constraint_mode = _lib.CONSTR_NONE
+
+    def __init__(self, sys, target_states, dt, device=None, dtype=np.float64, history=False,
+                 lanes_per_problem=0, alphas_per_lane=0):
+        if not isinstance(sys, System) and not hasattr(sys, "state_size"):
+            raise TypeError("sys must provide the systems.System interface")
+        self.target_states = target_states
+        ts = np.asarray(target_states)
+        if ts.ndim == 2:
+            self._batched = False
+            self._B = 1
+        elif ts.ndim == 3:
+            self._batched = True
+            self._B = ts.shape[0]
+        else:
+            raise ValueError("target_states must be (N, n) or (B, N, n)")
+        self.horizon = ts.shape[-2]
+        if ts.shape[-1] != sys.state_size:
+            raise ValueError("target_states last axis must equal sys.state_size")
+        self.dt = dt  # kept for interface parity; the dynamics use sys.dt (ilqr.py:20)
+        self.system = sys
+        self.n_states = sys.state_size
+        self.m_inputs = sys.control_size
+        self.Q = sys.Q
+        self.R = sys.R
+        self.Qf = sys.Q_f
+        self.maxIter = self._default_max_iter
+        self.LM_parameter = 0.0
+        lead = (self._B,) if self._batched else ()
+        self.min_cost = np.zeros(lead) if self._batched else 0.0
+        self.converge = np.zeros(lead, dtype=bool) if self._batched else False
+        self.states = np.zeros(lead + (self.horizon, self.n_states))
+        self.inputs = np.zeros(lead + (self.horizon - 1, self.m_inputs))
+        self.iterations = np.zeros(lead, dtype=np.int32) if self._batched else 0
+        self.status = np.zeros(lead, dtype=np.int32) if self._batched else 0
+        self._device = device
+        self._dtype = _np_dtype(dtype)
+        self._history = bool(history)
+        self._mapping = (int(lanes_per_problem), int(alphas_per_lane))
+        self._dev = None
+        self._k_cache = self._K_cache = None
+        self.cost_history = None
+        self.alpha_history = None
+
+    # -- hooks for the constrained variant ---------------------------------
+    def _alpha_floor(self):
+        return 1e-4  # ilqr.py:71
+
+    def _extra_desc(self):
+        return {}
+
+    def _extra_upload(self):
+        return {}
+
+    # -- device life cycle ----------------------------------------------------
+    def _key(self):
+        s = self.system
+        lim = (tuple(s.control_lower_limit), tuple(s.control_upper_limit)) if s.control_limited else None
+        return (self._B, self.horizon, int(self.maxIter), float(self.LM_parameter), float(s.dt),
+                np.asarray(self.Q).tobytes(), np.asarray(self.R).tobytes(), np.asarray(self.Qf).tobytes(),
+                bool(s.control_limited), lim, self._alpha_floor(), repr(sorted(self._extra_desc().items())))
+
+    def _ensure_device(self):
+        key = self._key()
+        if self._dev is None or self._dev_key != key:
+            if self._dev is not None:
+                self._dev.close()
+            self._dev = DeviceProblem(
+                self.system, self._B, self.horizon, self._dtype, self._device, max_iter=self.maxIter,
+                lm_parameter=self.LM_parameter, alpha_floor=self._alpha_floor(),
+                constraint_mode=self._constraint_mode, history=self._history,
+                lanes_per_problem=self._mapping[0], alphas_per_lane=self._mapping[1],
+                **self._extra_desc())
+            self._dev_key = key
+        return self._dev
+
+    def _lead(self, a, tail_ndim):
+        a = np.asarray(a)
+        return a if a.ndim == tail_ndim + 1 else a[None]
+
+    def upload(self):
+        """Copy targets, the current states/inputs guess and the converge flags to the device."""
+        dev = self._ensure_device()
+        dev.upload(self._lead(self.target_states, 2), self._lead(self.states, 2), self._lead(self.inputs, 2),
+                   converged=np.atleast_1d(np.asarray(self.converge)), **self._extra_upload())
+        dev.iters.zero_()
+        dev.status.zero_()
+        self._k_cache = self._K_cache = None
+        return dev
+
+    def solve_device(self):
+        """Run ``__call__`` on the device-resident data without any host transfer."""
+        self._ensure_device().solve(self.maxIter)
+
+    def download(self):
+        dev = self._dev
+        st, ui = dev.download_states(), dev.download_inputs()
+        J = dev.J.cpu().numpy().astype(np.float64)
+        cv = dev.converged.cpu().numpy().astype(bool)
+        it = dev.iters.cpu().numpy()
+        stt = dev.status.cpu().numpy()
+        if self._history:
+            self.cost_history = dev.hist_cost.cpu().numpy().T.copy()     # (B, maxIter)
+            self.alpha_history = dev.hist_alpha.cpu().numpy().T.copy()
+        # the reference mutates the caller's arrays in place (ilqr.py:56, :62): write back into
+        # the same objects when they are numpy arrays of the right shape
+        if self._batched:
+            self._assign("states", st)
+            self._assign("inputs", ui)
+            self.min_cost, self.converge, self.iterations, self.status = J, cv, it, stt
+        else:
+            self._assign("states", st[0])
+            self._assign("inputs", ui[0])
+            self.min_cost, self.converge = float(J[0]), bool(cv[0])
+            self.iterations, self.status = int(it[0]), int(stt[0])
+            if self._history:
+                self.cost_history, self.alpha_history = self.cost_history[0], self.alpha_history[0]
+
+    def _assign(self, name, value):
+        cur = getattr(self, name)
+        if isinstance(cur, np.ndarray) and cur.shape == value.shape and cur.flags.writeable:
+            cur[...] = value
+        else:
+            setattr(self, name, value.astype(np.float64))
+
+    # -- the reference entry point -----------------------------------------------
+    def __call__(self):
+        """``ilqr.py:107-114``: initial cost, then up to ``maxIter`` backward/forward
+        iterations per problem; returns ``self.states``."""
+        self.upload()
+        self.solve_device()
+        self.download()
+        return self.states
+
+    # gains of the last backward pass (ilqr.py:77-78), fetched on demand
+    @property
+    def k(self):
+        if self._k_cache is None and self._dev is not None:
+            v = self._dev.download_k()
+            self._k_cache = v if self._batched else v[0]
+        return self._k_cache
+
+    @property
+    def K(self):
+        if self._K_cache is None and self._dev is not None:
+            v = self._dev.download_K()
+            self._K_cache = v if self._batched else v[0]
+        return self._K_cache

@@ -1,0 +1,228 @@
+// C ABI of the batched iLQR library (declared in include/ilqr_amd.h).
+// Host-only logic: descriptor validation, dispatch to the kernel tables and
+// the iteration driver.  Nothing here allocates device memory.
+#include "host.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <new>
+
+using namespace ilqr;
+
+struct ilqr_handle {
+    HostCtx ctx;
+    const ModelOps *ops = nullptr;
+};
+
+static thread_local int g_last_hip_error = 0;
+
+static int hip_rc(hipError_t e) {
+    if (e == hipSuccess) return ILQR_OK;
+    g_last_hip_error = (int)e;
+    return ILQR_ERR_HIP;
+}
+
+static bool is_diag(const double *M, int n) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j)
+            if (i != j && M[i * n + j] != 0.0) return false;
+    return true;
+}
+
+// Number of step sizes the serial search of ilqr.py:53-74 can visit: alpha_j = 2^-j is
+// tried while every earlier alpha was >= the floor, i.e. 1 + #{j >= 0 : 2^-j >= floor}.
+static int alphas_from_floor(double floor_) {
+    if (!(floor_ > 0.0)) return -1;
+    int cnt = 1;
+    double a = 1.0;
+    while (a >= floor_ && cnt < 64) {
+        ++cnt;
+        a *= 0.5;
+    }
+    return cnt;
+}
+
+template <bool TO_TILED> static int relayout(const void *src, void *dst, int B, int rows, int elem, void *stream) {
+    if (!src || !dst || B <= 0 || rows <= 0) return ILQR_ERR_INVALID;
+    dim3 grid((rows + 63) / 64, (B + 63) / 64), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (elem == 8)
+        hipLaunchKernelGGL((relayout_kernel<double, TO_TILED>), grid, block, 0, s, (const double *)src, (double *)dst, B, rows);
+    else if (elem == 4)
+        hipLaunchKernelGGL((relayout_kernel<float, TO_TILED>), grid, block, 0, s, (const float *)src, (float *)dst, B, rows);
+    else
+        return ILQR_ERR_INVALID;
+    return hip_rc(hipGetLastError());
+}
+
+extern "C" {
+
+int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
+    if (!desc || !out) return ILQR_ERR_INVALID;
+    *out = nullptr;
+    const ilqr_desc &d = *desc;
+    if (d.B <= 0 || d.N < 2 || d.n <= 0 || d.m <= 0 || d.n > ILQR_MAX_N || d.m > ILQR_MAX_M) return ILQR_ERR_INVALID;
+    if (d.dtype != ILQR_F64 && d.dtype != ILQR_F32) return ILQR_ERR_INVALID;
+    if (d.constraint_mode & ~(ILQR_CONSTR_BOXQP | ILQR_CONSTR_BARRIER)) return ILQR_ERR_INVALID;
+    if (!(d.dt == d.dt)) return ILQR_ERR_INVALID;
+    int want_n = 0, want_m = 0;
+    const ModelOps *ops = nullptr;
+    bool diag = is_diag(d.Q, d.n) && is_diag(d.Qf, d.n) && is_diag(d.R, d.m);
+    switch (d.model) {
+    case ILQR_MODEL_CAR: want_n = 4; want_m = 2; ops = ops_car(d.dtype, diag); break;
+    case ILQR_MODEL_CARACC: want_n = 5; want_m = 2; ops = ops_caracc(d.dtype, diag); break;
+    case ILQR_MODEL_DUBINS: want_n = 3; want_m = 2; ops = ops_dubins(d.dtype, diag); break;
+    default: return ILQR_ERR_UNSUPPORTED;
+    }
+    if (d.n != want_n || d.m != want_m) return ILQR_ERR_INVALID;
+    if (!ops) return ILQR_ERR_UNSUPPORTED;
+    if ((d.constraint_mode & ILQR_CONSTR_BARRIER)) {
+        // the constraint functions are written for the Car state layout (constraints.py:12)
+        if (d.model != ILQR_MODEL_CAR) return ILQR_ERR_UNSUPPORTED;
+        if (!(d.barrier_mu >= 0.0) || !(d.barrier_delta > 0.0)) return ILQR_ERR_INVALID;
+    }
+    if ((d.constraint_mode & ILQR_CONSTR_BOXQP) || d.control_limited)
+        for (int j = 0; j < d.m; ++j)
+            if (!(d.lo[j] <= d.hi[j])) return ILQR_ERR_INVALID;
+    int na = d.n_alphas > 0 ? d.n_alphas : alphas_from_floor(d.alpha_floor);
+    if (na <= 0 || na > 64) return ILQR_ERR_INVALID;
+    int L = d.lanes_per_problem, A = d.alphas_per_lane;
+    if (L == 0 && A == 0) {
+        L = 16;
+        A = 1;
+    } else if (L == 0 || A == 0) {
+        return ILQR_ERR_INVALID;
+    }
+    {
+        const int key = L * 100 + A;
+        const int ok[] = {1601, 802, 404, 116, 801, 401, 104, 204};
+        bool found = false;
+        for (int v : ok) found = found || (v == key);
+        if (!found) return ILQR_ERR_UNSUPPORTED;
+    }
+    ilqr_handle *h = new (std::nothrow) ilqr_handle();
+    if (!h) return ILQR_ERR_INVALID;
+    h->ctx.d = d;
+    std::memset(&h->ctx.b, 0, sizeof(h->ctx.b));
+    h->ctx.diag = diag;
+    h->ctx.n_alphas = na;
+    h->ctx.L = L;
+    h->ctx.A = A;
+    h->ops = ops;
+    *out = h;
+    return ILQR_OK;
+}
+
+void ilqr_destroy(ilqr_handle *h) { delete h; }
+
+static size_t jtry_bytes(const ilqr_handle *h) {
+    const size_t e = h->ctx.d.dtype == ILQR_F64 ? 8 : 4;
+    return ((size_t)h->ctx.d.B * e + 255) & ~(size_t)255;
+}
+
+// layout of `work`: [ trial cost of the accepted step size, per problem | 256 B of counters ]
+size_t ilqr_workspace_bytes(const ilqr_handle *h) { return h ? jtry_bytes(h) + 256 : 0; }
+
+int32_t ilqr_num_alphas(const ilqr_handle *h) { return h ? h->ctx.n_alphas : 0; }
+
+int ilqr_bind(ilqr_handle *h, const ilqr_buffers *b) {
+    if (!h || !b) return ILQR_ERR_INVALID;
+    if (!b->X || !b->U || !b->Xref || !b->K || !b->k || !b->J || !b->converged || !b->iters || !b->alpha_idx || !b->work)
+        return ILQR_ERR_NOT_BOUND;
+    if ((h->ctx.d.constraint_mode & ILQR_CONSTR_BARRIER) && (!b->centers || !b->radius)) return ILQR_ERR_NOT_BOUND;
+    if ((b->hist_cost || b->hist_alpha) && b->hist_capacity <= 0) return ILQR_ERR_INVALID;
+    h->ctx.b = *b;
+    h->ctx.bound = true;
+    return ILQR_OK;
+}
+
+#define REQUIRE_BOUND(h)                          \
+    if (!(h)) return ILQR_ERR_INVALID;            \
+    if (!(h)->ctx.bound) return ILQR_ERR_NOT_BOUND;
+
+int ilqr_initial_cost(ilqr_handle *h, void *stream) {
+    REQUIRE_BOUND(h);
+    return hip_rc(h->ops->cost(h->ctx, 0, (hipStream_t)stream));
+}
+
+int ilqr_backward(ilqr_handle *h, void *stream) {
+    REQUIRE_BOUND(h);
+    return hip_rc(h->ops->backward(h->ctx, 0, (hipStream_t)stream));
+}
+
+int ilqr_forward_evaluate(ilqr_handle *h, void *stream) {
+    REQUIRE_BOUND(h);
+    return hip_rc(h->ops->evaluate(h->ctx, 0, (hipStream_t)stream));
+}
+
+int ilqr_forward_commit(ilqr_handle *h, int32_t iteration, void *stream) {
+    REQUIRE_BOUND(h);
+    if (iteration < 0) return ILQR_ERR_INVALID;
+    return hip_rc(h->ops->commit(h->ctx, iteration, (hipStream_t)stream));
+}
+
+int ilqr_forward(ilqr_handle *h, int32_t iteration, void *stream) {
+    int rc = ilqr_forward_evaluate(h, stream);
+    if (rc != ILQR_OK) return rc;
+    return ilqr_forward_commit(h, iteration, stream);
+}
+
+int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream) {
+    REQUIRE_BOUND(h);
+    if (max_iter < 0) return ILQR_ERR_INVALID;
+    int rc = ilqr_initial_cost(h, stream);
+    for (int it = 0; it < max_iter && rc == ILQR_OK; ++it) {
+        rc = ilqr_backward(h, stream);
+        if (rc == ILQR_OK) rc = ilqr_forward(h, it, stream);
+    }
+    return rc;
+}
+
+namespace {
+__global__ void count_active_kernel(const int32_t *conv, int B, int32_t *out) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    bool a = b < B && conv[b] == 0;
+    unsigned long long m = __ballot(a);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (int)__popcll(m));
+}
+} // namespace
+
+int ilqr_active_count(ilqr_handle *h, void *stream, int32_t *out) {
+    REQUIRE_BOUND(h);
+    if (!out) return ILQR_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    int32_t *counter = (int32_t *)((char *)h->ctx.b.work + jtry_bytes(h));
+    hipError_t e = hipMemsetAsync(counter, 0, sizeof(int32_t), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(count_active_kernel, dim3((h->ctx.d.B + 255) / 256), dim3(256), 0, s, h->ctx.b.converged, h->ctx.d.B, counter);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, counter, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    return hip_rc(e);
+}
+
+int ilqr_to_tiled(const void *aos, void *tiled, int32_t B, int32_t rows, int32_t elem_bytes, void *stream) {
+    return relayout<true>(aos, tiled, B, rows, elem_bytes, stream);
+}
+
+int ilqr_from_tiled(const void *tiled, void *aos, int32_t B, int32_t rows, int32_t elem_bytes, void *stream) {
+    return relayout<false>(tiled, aos, B, rows, elem_bytes, stream);
+}
+
+const char *ilqr_strerror(int code) {
+    switch (code) {
+    case ILQR_OK: return "ok";
+    case ILQR_ERR_INVALID: return "invalid argument or descriptor field";
+    case ILQR_ERR_UNSUPPORTED: return "model/dtype/shape combination not built into this library";
+    case ILQR_ERR_NOT_BOUND: return "a required device buffer is not bound";
+    case ILQR_ERR_HIP: return "HIP runtime error (see ilqr_last_hip_error)";
+    default: return "unknown error code";
+    }
+}
+
+int ilqr_last_hip_error(void) { return g_last_hip_error; }
+int32_t ilqr_desc_size(void) { return (int32_t)sizeof(ilqr_desc); }
+int32_t ilqr_buffers_size(void) { return (int32_t)sizeof(ilqr_buffers); }
+
+} // extern "C"

@@ -1,0 +1,164 @@
+// Host-side glue between the C ABI (api.hip) and the templated kernels:
+// a type-erased launch table per (model, dtype, diagonal-cost) combination.
+#pragma once
+#include "../../include/ilqr_amd.h"
+#include "kernels.hpp"
+
+namespace ilqr {
+
+struct HostCtx {
+    ilqr_desc d;
+    ilqr_buffers b;
+    bool bound = false;
+    bool diag = false;   // Q, R, Qf all diagonal
+    int n_alphas = 0;
+    int L = 16, A = 1;   // forward mapping
+};
+
+typedef hipError_t (*launch_fn)(const HostCtx &, int it, hipStream_t);
+struct ModelOps {
+    launch_fn cost, backward, evaluate, commit;
+};
+
+// one table per translation unit (ops_*.hip); nullptr if the combination is not built
+const ModelOps *ops_car(int dtype, bool diag);
+const ModelOps *ops_caracc(int dtype, bool diag);
+const ModelOps *ops_dubins(int dtype, bool diag);
+
+template <typename T, int NX, int NU> static Params<T, NX, NU> make_params(const HostCtx &c) {
+    Params<T, NX, NU> p;
+    const ilqr_desc &d = c.d;
+    const ilqr_buffers &b = c.b;
+    p.X = (T *)b.X;
+    p.U = (T *)b.U;
+    p.Xref = (const T *)b.Xref;
+    p.K = (T *)b.K;
+    p.k = (T *)b.k;
+    p.J = (T *)b.J;
+    p.Jtry = (T *)b.work;
+    p.converged = b.converged;
+    p.iters = b.iters;
+    p.alpha_idx = b.alpha_idx;
+    p.status = b.status;
+    p.centers = (const T *)b.centers;
+    p.radius = (const T *)b.radius;
+    p.ltvA = (const T *)b.ltv_A;
+    p.ltvB = (const T *)b.ltv_B;
+    p.hist_cost = (T *)b.hist_cost;
+    p.hist_alpha = b.hist_alpha;
+    p.hist_cap = (b.hist_cost || b.hist_alpha) ? b.hist_capacity : 0;
+    p.B = d.B;
+    p.N = d.N;
+    p.n_alphas = c.n_alphas;
+    p.control_limited = d.control_limited;
+    p.boxqp = (d.constraint_mode & ILQR_CONSTR_BOXQP) ? 1 : 0;
+    p.barrier = (d.constraint_mode & ILQR_CONSTR_BARRIER) ? 1 : 0;
+    p.dt = (T)d.dt;
+    p.lm = (T)d.lm_parameter;
+    p.lambda = (T)d.input_limit_lambda;
+    p.mu = (T)d.barrier_mu;
+    p.delta = (T)d.barrier_delta;
+    p.vlo = (T)d.vel_bounds[0];
+    p.vhi = (T)d.vel_bounds[1];
+    for (int i = 0; i < NX * NX; ++i) {
+        p.Q[i] = (T)d.Q[i];
+        p.Qf[i] = (T)d.Qf[i];
+        p.Q2[i] = (T)(2.0 * d.Q[i]);
+        p.Qf2[i] = (T)(2.0 * d.Qf[i]);
+    }
+    for (int i = 0; i < NU * NU; ++i) {
+        p.R[i] = (T)d.R[i];
+        p.R2[i] = (T)(2.0 * d.R[i]);
+    }
+    for (int i = 0; i < NU; ++i) {
+        p.lo[i] = (T)d.lo[i];
+        p.hi[i] = (T)d.hi[i];
+    }
+    return p;
+}
+
+// prefetch depth (time steps in flight per lane) of the lane-per-problem kernels
+constexpr int PF_BACKWARD = 3;
+constexpr int PF_COMMIT = 2;
+
+template <typename T, template <typename> class MT, bool DIAG> struct Launch {
+    using M = MT<T>;
+    static constexpr int NX = M::NX, NU = M::NU;
+
+    static bool barrier_on(const HostCtx &c) { return (c.d.constraint_mode & ILQR_CONSTR_BARRIER) != 0; }
+
+    static hipError_t cost(const HostCtx &c, int, hipStream_t s) {
+        auto p = make_params<T, NX, NU>(c);
+        const dim3 grid((c.d.B + 63) / 64), block(64);
+        if constexpr (M::HAS_BARRIER) {
+            if (barrier_on(c)) {
+                hipLaunchKernelGGL((cost_kernel<T, M, DIAG, true>), grid, block, 0, s, p);
+                return hipGetLastError();
+            }
+        }
+        if (barrier_on(c)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((cost_kernel<T, M, DIAG, false>), grid, block, 0, s, p);
+        return hipGetLastError();
+    }
+    template <int CONSTR> static hipError_t backward_c(const HostCtx &c, hipStream_t s) {
+        auto p = make_params<T, NX, NU>(c);
+        hipLaunchKernelGGL((backward_kernel<T, M, DIAG, CONSTR, PF_BACKWARD>), dim3((c.d.B + 63) / 64), dim3(64), 0, s, p);
+        return hipGetLastError();
+    }
+    static hipError_t backward(const HostCtx &c, int, hipStream_t s) {
+        const int mode = c.d.constraint_mode & 3;
+        if constexpr (M::HAS_BARRIER) {
+            if (mode == 2) return backward_c<2>(c, s);
+            if (mode == 3) return backward_c<3>(c, s);
+        }
+        if (mode == 0) return backward_c<0>(c, s);
+        if (mode == 1) return backward_c<1>(c, s);
+        return hipErrorInvalidValue;
+    }
+    template <bool BARRIER, int L, int A> static hipError_t eval_la(const HostCtx &c, hipStream_t s) {
+        auto p = make_params<T, NX, NU>(c);
+        const int ppw = 64 / L;                        // problems per wave
+        const long waves = ((long)c.d.B + ppw - 1) / ppw;
+        const int blocks = (int)((waves + 3) / 4);     // 4 waves per workgroup
+        hipLaunchKernelGGL((evaluate_kernel<T, M, DIAG, BARRIER, L, A>), dim3(blocks), dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
+    template <bool BARRIER> static hipError_t eval_b(const HostCtx &c, hipStream_t s) {
+        const int key = c.L * 100 + c.A;
+        switch (key) {
+        case 1601: return eval_la<BARRIER, 16, 1>(c, s);
+        case 802: return eval_la<BARRIER, 8, 2>(c, s);
+        case 404: return eval_la<BARRIER, 4, 4>(c, s);
+        case 116: return eval_la<BARRIER, 1, 16>(c, s);
+        case 801: return eval_la<BARRIER, 8, 1>(c, s);
+        case 401: return eval_la<BARRIER, 4, 1>(c, s);
+        case 104: return eval_la<BARRIER, 1, 4>(c, s);
+        case 204: return eval_la<BARRIER, 2, 4>(c, s);
+        default: return hipErrorInvalidValue;
+        }
+    }
+    static hipError_t evaluate(const HostCtx &c, int, hipStream_t s) {
+        if constexpr (M::HAS_BARRIER) {
+            if (barrier_on(c)) return eval_b<true>(c, s);
+        }
+        if (barrier_on(c)) return hipErrorInvalidValue;
+        return eval_b<false>(c, s);
+    }
+    static hipError_t commit(const HostCtx &c, int it, hipStream_t s) {
+        auto p = make_params<T, NX, NU>(c);
+        hipLaunchKernelGGL((commit_kernel<T, M, PF_COMMIT>), dim3((c.d.B + 63) / 64), dim3(64), 0, s, p, it);
+        return hipGetLastError();
+    }
+    static const ModelOps *table() {
+        static const ModelOps ops = {&cost, &backward, &evaluate, &commit};
+        return &ops;
+    }
+};
+
+template <template <typename> class MT> static const ModelOps *ops_for(int dtype, bool diag) {
+    if (dtype == ILQR_F64) return diag ? Launch<double, MT, true>::table() : Launch<double, MT, false>::table();
+    if (dtype == ILQR_F32) return diag ? Launch<float, MT, true>::table() : Launch<float, MT, false>::table();
+    return nullptr;
+}
+
+} // namespace ilqr

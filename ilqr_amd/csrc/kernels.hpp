@@ -1,0 +1,942 @@
+// Batched iLQR kernels for gfx950 (MI355X): one launch per solver phase, each
+// covering the whole horizon for every problem of the batch.
+//
+//   cost_kernel      ilqr.py:36-46   initial cost, one lane per problem
+//   backward_kernel  ilqr.py:76-105  fused linearise + quadratise + Riccati sweep
+//                    (cilqr.py:112-134 box-QP branch, barrier terms) one lane per problem
+//   evaluate_kernel  ilqr.py:53-74   every line-search step size rolled out in parallel:
+//                    L lanes of a wave share one problem, each lane carries A step sizes
+//   commit_kernel    ilqr.py:56-63   the winning step size rolled out again, in place
+//
+// All trajectory arrays are structure-of-arrays with the batch index innermost,
+// so lane b of a wave touches address base + b: every global access of the
+// lane-per-problem kernels is a full-width coalesced row.  The per-problem
+// matrices (n <= 12, m <= 4) live in registers; the time loop is sequential
+// and software-prefetches the next steps' rows while the current step computes.
+//
+// Arithmetic is written with explicit fma() and the file is compiled with
+// -ffp-contract=off: the evaluate and the commit kernel then execute the same
+// rounding sequence, so the committed trajectory has exactly the cost the
+// line search accepted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ilqr {
+
+// per-problem status bits (same values as ILQR_STATUS_* of the C header)
+constexpr int ILQR_STATUS_NONPD_ = 1, ILQR_STATUS_SINGULAR_ = 2, ILQR_STATUS_NONFINITE_ = 4;
+
+// ---------------------------------------------------------------- scalars
+template <typename T> __device__ __forceinline__ T fma_(T a, T b, T c);
+template <> __device__ __forceinline__ double fma_<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <> __device__ __forceinline__ float fma_<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+__device__ __forceinline__ void sincos_(double x, double &s, double &c) { sincos(x, &s, &c); }
+__device__ __forceinline__ void sincos_(float x, float &s, float &c) { sincosf(x, &s, &c); }
+__device__ __forceinline__ double log_(double x) { return log(x); }
+__device__ __forceinline__ float log_(float x) { return logf(x); }
+__device__ __forceinline__ double fabs_(double x) { return fabs(x); }
+__device__ __forceinline__ float fabs_(float x) { return fabsf(x); }
+
+template <typename T> __device__ __forceinline__ T pow2_neg(int a);
+template <> __device__ __forceinline__ double pow2_neg<double>(int a) { return __builtin_ldexp(1.0, -a); }
+template <> __device__ __forceinline__ float pow2_neg<float>(int a) { return __builtin_ldexpf(1.0f, -a); }
+
+template <typename T> __device__ __forceinline__ T inf_();
+template <> __device__ __forceinline__ double inf_<double>() { return __builtin_huge_val(); }
+template <> __device__ __forceinline__ float inf_<float>() { return __builtin_huge_valf(); }
+
+// ---------------------------------------------------------------- layout
+// Trajectory arrays are tiled: [tile = b / 64][row][lane = b % 64], one tile per
+// 64 consecutive problems, rows = time step x component.  A wave therefore
+// streams ONE contiguous region per array over the whole horizon, addressed by a
+// single base pointer plus small constant offsets, and every access is a full
+// 512-byte (fp64) row.
+constexpr int TILE = 64;
+template <typename T> __device__ __forceinline__ T *tile_ptr(T *base, int tile, int rows, int lane) {
+    return base + (size_t)tile * (size_t)rows * TILE + lane;
+}
+
+// ---------------------------------------------------------------- parameters
+// Passed by value as the kernel argument.  Q2/R2/Qf2 are 2Q, 2R, 2Qf (exact
+// scalings) used by the quadratisation (ilqr.py:79-92).
+template <typename T, int NX, int NU> struct Params {
+    T *X, *U;
+    const T *Xref;
+    T *K, *k;
+    T *J, *Jtry;
+    int32_t *converged, *iters, *alpha_idx, *status;
+    const T *centers, *radius;
+    const T *ltvA, *ltvB;
+    T *hist_cost;
+    int32_t *hist_alpha;
+    int32_t hist_cap;
+    int32_t B, N;
+    int32_t n_alphas;
+    int32_t control_limited, boxqp, barrier;
+    T dt, lm, lambda, mu, delta, vlo, vhi;
+    T Q[NX * NX], R[NU * NU], Qf[NX * NX];
+    T Q2[NX * NX], R2[NU * NU], Qf2[NX * NX];
+    T lo[NU], hi[NU];
+};
+
+// ---------------------------------------------------------------- models
+// Each model states the discrete dynamics and its Jacobians with the operation
+// order of the reference (x + rate*dt) and declares which Jacobian entries can
+// be non-zero, so the generic Riccati code skips structural zeros at compile time.
+
+template <typename T> struct CarModel { // systems.py:27-57
+    static constexpr int NX = 4, NU = 2;
+    static constexpr bool HAS_BARRIER = true; // state layout of constraints.py:12 (px, py, v, .)
+    static constexpr bool fx_nz(int i, int j) { return i == j || (i < 2 && j >= 2); }
+    static constexpr bool fx_one(int i, int j) { return i == j; }
+    static constexpr bool fu_nz(int i, int j) { return (i == 2 && j == 0) || (i == 3 && j == 1); }
+    template <class P>
+    static __device__ __forceinline__ void step(const P &p, int, const T (&x)[NX], const T (&u)[NU], T (&xn)[NX]) {
+        T s, c;
+        sincos_(x[3], s, c);
+        xn[0] = fma_(x[2] * c, p.dt, x[0]);
+        xn[1] = fma_(x[2] * s, p.dt, x[1]);
+        xn[2] = fma_(u[0], p.dt, x[2]);
+        xn[3] = fma_(u[1], p.dt, x[3]);
+    }
+    template <class P>
+    static __device__ __forceinline__ void jac(const P &p, int, const T (&x)[NX], const T (&)[NU], T (&fx)[NX][NX], T (&fu)[NX][NU]) {
+        T s, c;
+        sincos_(x[3], s, c);
+        fx[0][2] = c * p.dt;
+        fx[0][3] = (-s * x[2]) * p.dt;
+        fx[1][2] = s * p.dt;
+        fx[1][3] = (c * x[2]) * p.dt;
+        fu[2][0] = p.dt;
+        fu[3][1] = p.dt;
+    }
+};
+
+template <typename T> struct CarAccModel { // systems.py:59-90
+    static constexpr int NX = 5, NU = 2;
+    static constexpr bool HAS_BARRIER = false;
+    static constexpr bool fx_nz(int i, int j) { return i == j || (i < 2 && (j == 2 || j == 4)) || (i == 2 && j == 3); }
+    static constexpr bool fx_one(int i, int j) { return i == j; }
+    static constexpr bool fu_nz(int i, int j) { return (i == 3 && j == 0) || (i == 4 && j == 1); }
+    template <class P>
+    static __device__ __forceinline__ void step(const P &p, int, const T (&x)[NX], const T (&u)[NU], T (&xn)[NX]) {
+        T s, c;
+        sincos_(x[4], s, c);
+        xn[0] = fma_(x[2] * c, p.dt, x[0]);
+        xn[1] = fma_(x[2] * s, p.dt, x[1]);
+        xn[2] = fma_(x[3], p.dt, x[2]);
+        xn[3] = fma_(u[0], p.dt, x[3]);
+        xn[4] = fma_(u[1], p.dt, x[4]);
+    }
+    template <class P>
+    static __device__ __forceinline__ void jac(const P &p, int, const T (&x)[NX], const T (&)[NU], T (&fx)[NX][NX], T (&fu)[NX][NU]) {
+        T s, c;
+        sincos_(x[4], s, c);
+        fx[0][2] = c * p.dt;
+        fx[0][4] = (-s * x[2]) * p.dt;
+        fx[1][2] = s * p.dt;
+        fx[1][4] = (c * x[2]) * p.dt;
+        fx[2][3] = p.dt;
+        fu[3][0] = p.dt;
+        fu[4][1] = p.dt;
+    }
+};
+
+template <typename T> struct DubinsModel { // systems.py:92-121
+    static constexpr int NX = 3, NU = 2;
+    static constexpr bool HAS_BARRIER = false;
+    static constexpr bool fx_nz(int i, int j) { return i == j || (i < 2 && j == 2); }
+    static constexpr bool fx_one(int i, int j) { return i == j; }
+    static constexpr bool fu_nz(int i, int j) { return j == 0 || (i == 2 && j == 1); }
+    template <class P>
+    static __device__ __forceinline__ void step(const P &p, int, const T (&x)[NX], const T (&u)[NU], T (&xn)[NX]) {
+        T s, c;
+        sincos_(x[2], s, c);
+        xn[0] = fma_(u[0] * c, p.dt, x[0]);
+        xn[1] = fma_(u[0] * s, p.dt, x[1]);
+        xn[2] = fma_(u[0] * u[1], p.dt, x[2]);
+    }
+    template <class P>
+    static __device__ __forceinline__ void jac(const P &p, int, const T (&x)[NX], const T (&u)[NU], T (&fx)[NX][NX], T (&fu)[NX][NU]) {
+        T s, c;
+        sincos_(x[2], s, c);
+        fx[0][2] = (-s * u[0]) * p.dt;
+        fx[1][2] = (c * u[0]) * p.dt;
+        fu[0][0] = c * p.dt;
+        fu[1][0] = s * p.dt;
+        fu[2][0] = u[1] * p.dt;
+        fu[2][1] = u[0] * p.dt;
+    }
+};
+
+// ---------------------------------------------------------------- cost pieces
+// e' W e with W dense row-major, as (e' W) e (ilqr.py:42), or diagonal.
+template <typename T, int D, bool DIAG>
+__device__ __forceinline__ T quad_(const T *W, const T (&e)[D]) {
+    T s = T(0);
+    if (DIAG) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            T w = W[i * D + i] * e[i];
+            s = (i == 0) ? w * e[i] : fma_(w, e[i], s);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            T r = e[0] * W[0 * D + j];
+#pragma unroll
+            for (int i = 1; i < D; ++i) r = fma_(e[i], W[i * D + j], r);
+            s = (j == 0) ? r * e[j] : fma_(r, e[j], s);
+        }
+    }
+    return s;
+}
+
+// relaxed log barrier: -log z above delta, C2 quadratic extension below
+template <typename T>
+__device__ __forceinline__ T relaxed_barrier(T z, T delta, T &d1, T &d2) {
+    if (z > delta) {
+        T r = T(1) / z;
+        d1 = -r;
+        d2 = r * r;
+        return -log_(z);
+    }
+    T id = T(1) / delta;
+    T w = (z - T(2) * delta) * id;
+    d1 = w * id;
+    d2 = id * id;
+    return fma_(T(0.5), fma_(w, w, T(-1)), -log_(delta));
+}
+
+// barrier value at a state (components 0,1 position, 2 speed: constraints.py:20-26);
+// optionally accumulates gradient and Hessian into lx / lxx
+template <typename T, int NX, bool WITH_DERIV, class P>
+__device__ __forceinline__ T barrier_terms(const P &p, const T (&x)[NX], T cx, T cy, T r, T (&lx)[NX], T (&lxx)[NX][NX]) {
+    T d1, d2, e1, e2, f1, f2;
+    T ex = x[0] - cx, ey = x[1] - cy;
+    T h = fma_(ex, ex, fma_(ey, ey, -(r * r)));
+    T val = relaxed_barrier(-h, p.delta, d1, d2);
+    T v1 = relaxed_barrier(x[2] - p.vlo, p.delta, e1, e2);
+    T v2 = relaxed_barrier(p.vhi - x[2], p.delta, f1, f2);
+    if (WITH_DERIV) {
+        T gx = T(-2) * ex, gy = T(-2) * ey;
+        lx[0] = fma_(p.mu * d1, gx, lx[0]);
+        lx[1] = fma_(p.mu * d1, gy, lx[1]);
+        lxx[0][0] += p.mu * fma_(d2 * gx, gx, T(-2) * d1);
+        lxx[0][1] += p.mu * (d2 * gx * gy);
+        lxx[1][0] += p.mu * (d2 * gy * gx);
+        lxx[1][1] += p.mu * fma_(d2 * gy, gy, T(-2) * d1);
+        lx[2] += p.mu * (e1 - f1);
+        lxx[2][2] += p.mu * (e2 + f2);
+    }
+    return p.mu * ((val + v1) + v2);
+}
+
+// ---------------------------------------------------------------- cost kernel
+template <typename T, class M, bool DIAG, bool BARRIER>
+__global__ __launch_bounds__(64) void cost_kernel(Params<T, M::NX, M::NU> p) {
+    constexpr int NX = M::NX, NU = M::NU;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= p.B) return;
+    constexpr bool BARRIER_ = BARRIER;
+    const int tile = b >> 6, ln = b & 63;
+    const T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
+    const T *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
+    const T *Ut = tile_ptr(p.U, tile, (p.N - 1) * NU, ln);
+    const T *Cp = BARRIER_ ? tile_ptr(p.centers, tile, p.N * 2, ln) : nullptr;
+    const T *Dp = BARRIER_ ? tile_ptr(p.radius, tile, p.N, ln) : nullptr;
+    T cost = T(0);
+    T dummy_lx[NX], dummy_lxx[NX][NX];
+    for (int t = 0; t < p.N - 1; ++t) {
+        T x[NX], e[NX], u[NU];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            x[i] = Xt[(t * NX + i) * TILE];
+            e[i] = x[i] - Rt[(t * NX + i) * TILE];
+        }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) u[i] = Ut[(t * NU + i) * TILE];
+        T stage = quad_<T, NX, DIAG>(p.Q, e) + quad_<T, NU, DIAG>(p.R, u);
+        if (BARRIER && t > 0)
+            stage += barrier_terms<T, NX, false>(p, x, Cp[(t * 2 + 0) * TILE],
+                                                 Cp[(t * 2 + 1) * TILE],
+                                                 Dp[t * TILE], dummy_lx, dummy_lxx);
+        cost += stage;
+    }
+    {
+        const int t = p.N - 1;
+        T x[NX], e[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            x[i] = Xt[(t * NX + i) * TILE];
+            e[i] = x[i] - Rt[(t * NX + i) * TILE];
+        }
+        T term = quad_<T, NX, DIAG>(p.Qf, e);
+        if (BARRIER)
+            term += barrier_terms<T, NX, false>(p, x, Cp[(t * 2 + 0) * TILE],
+                                                Cp[(t * 2 + 1) * TILE],
+                                                Dp[t * TILE], dummy_lx, dummy_lxx);
+        cost += term;
+    }
+    p.J[b] = cost;
+}
+
+// ---------------------------------------------------------------- Quu solve
+// Solves Quu * [k | K] = -[Qu | Qux] for m <= 4 by the square-root-free
+// Cholesky factorisation (L D L') of the lower triangle.  If a pivot is not
+// positive the matrix is not positive definite: fall back to LU with partial
+// pivoting on the full matrix, which is what numpy.linalg.inv does
+// (ilqr.py:99), and flag the problem.
+template <typename T, int NU, int NR>
+__device__ __forceinline__ int solve_quu(const T (&A)[NU][NU], T (&Bm)[NU][NR]) {
+    // Bm holds the right-hand sides on entry (already negated) and the solution on exit
+    T L[NU][NU], d[NU], dinv[NU];
+    bool pd = true;
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        T dj = A[j][j];
+#pragma unroll
+        for (int q = 0; q < j; ++q) dj = fma_(-(L[j][q] * L[j][q]), d[q], dj);
+        pd = pd && (dj > T(0));
+        d[j] = dj;
+        dinv[j] = T(1) / dj;
+#pragma unroll
+        for (int i = j + 1; i < NU; ++i) {
+            T s = A[i][j];
+#pragma unroll
+            for (int q = 0; q < j; ++q) s = fma_(-(L[i][q] * L[j][q]), d[q], s);
+            L[i][j] = s * dinv[j];
+        }
+    }
+    if (__builtin_expect(pd, 1)) {
+#pragma unroll
+        for (int c = 0; c < NR; ++c) {
+            T y[NU];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) { // forward: L y = b
+                T s = Bm[i][c];
+#pragma unroll
+                for (int q = 0; q < i; ++q) s = fma_(-L[i][q], y[q], s);
+                y[i] = s;
+            }
+#pragma unroll
+            for (int i = NU - 1; i >= 0; --i) { // backward: L' x = D^-1 y
+                T s = y[i] * dinv[i];
+#pragma unroll
+                for (int q = i + 1; q < NU; ++q) s = fma_(-L[q][i], Bm[q][c], s);
+                Bm[i][c] = s;
+            }
+        }
+        return 0;
+    }
+    // pivoted LU (rare path; divergent lanes only)
+    T LU[NU][NU];
+    int piv[NU];
+    int rc = ILQR_STATUS_NONPD_;
+#pragma unroll
+    for (int i = 0; i < NU; ++i)
+#pragma unroll
+        for (int j = 0; j < NU; ++j) LU[i][j] = A[i][j];
+    for (int c = 0; c < NU; ++c) {
+        int pr = c;
+        T best = fabs_(LU[c][c]);
+        for (int r = c + 1; r < NU; ++r)
+            if (fabs_(LU[r][c]) > best) { best = fabs_(LU[r][c]); pr = r; }
+        piv[c] = pr;
+        if (best == T(0)) rc |= ILQR_STATUS_SINGULAR_;
+        if (pr != c) {
+            for (int j = 0; j < NU; ++j) { T t = LU[c][j]; LU[c][j] = LU[pr][j]; LU[pr][j] = t; }
+            for (int j = 0; j < NR; ++j) { T t = Bm[c][j]; Bm[c][j] = Bm[pr][j]; Bm[pr][j] = t; }
+        }
+        T inv = T(1) / LU[c][c];
+        for (int r = c + 1; r < NU; ++r) {
+            LU[r][c] *= inv;
+            for (int j = c + 1; j < NU; ++j) LU[r][j] = fma_(-LU[r][c], LU[c][j], LU[r][j]);
+            for (int j = 0; j < NR; ++j) Bm[r][j] = fma_(-LU[r][c], Bm[c][j], Bm[r][j]);
+        }
+    }
+    (void)piv;
+    for (int j = 0; j < NR; ++j)
+        for (int i = NU - 1; i >= 0; --i) {
+            T s = Bm[i][j];
+            for (int q = i + 1; q < NU; ++q) s = fma_(-LU[i][q], Bm[q][j], s);
+            Bm[i][j] = s / LU[i][i];
+        }
+    return rc;
+}
+
+// ---------------------------------------------------------------- backward
+// One Riccati step: consumes (x, u, xref) of step t and the value function of
+// step t+1, produces the gains of step t and the value function of step t.
+template <typename T, class M, bool DIAG, int CONSTR, class P>
+__device__ __forceinline__ int riccati_step(const P &p, int t, const T (&x)[M::NX], const T (&u)[M::NU], const T (&xr)[M::NX],
+                                            T bcx, T bcy, T brad, T (&Vx)[M::NX], T (&Vxx)[M::NX][M::NX],
+                                            T (&Kt)[M::NU][M::NX], T (&kt)[M::NU]) {
+    constexpr int NX = M::NX, NU = M::NU;
+    T e[NX], lx[NX], lu[NU], lxx[NX][NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) e[i] = x[i] - xr[i];
+    // l_x = 2Q(x - xref), l_u = 2Ru, l_xx = 2Q, l_uu = 2R (ilqr.py:83-84, :91-92)
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        if (DIAG) {
+            lx[i] = p.Q2[i * NX + i] * e[i];
+        } else {
+            T s = p.Q2[i * NX] * e[0];
+#pragma unroll
+            for (int j = 1; j < NX; ++j) s = fma_(p.Q2[i * NX + j], e[j], s);
+            lx[i] = s;
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) lxx[i][j] = (DIAG && i != j) ? T(0) : p.Q2[i * NX + j];
+    }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        if (DIAG) {
+            lu[i] = p.R2[i * NU + i] * u[i];
+        } else {
+            T s = p.R2[i * NU] * u[0];
+#pragma unroll
+            for (int j = 1; j < NU; ++j) s = fma_(p.R2[i * NU + j], u[j], s);
+            lu[i] = s;
+        }
+    }
+    if ((CONSTR & 2) && t > 0) barrier_terms<T, NX, true>(p, x, bcx, bcy, brad, lx, lxx);
+
+    T fx[NX][NX], fu[NX][NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) fx[i][j] = M::fx_one(i, j) ? T(1) : T(0);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) fu[i][j] = T(0);
+    }
+    M::jac(p, t, x, u, fx, fu);
+
+    // Qx = l_x + fx' Vx ; Qu = l_u + fu' Vx (ilqr.py:93-94)
+    T Qx[NX], Qu[NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        T s = lx[i];
+#pragma unroll
+        for (int q = 0; q < NX; ++q)
+            if (M::fx_nz(q, i)) s = M::fx_one(q, i) ? s + Vx[q] : fma_(fx[q][i], Vx[q], s);
+        Qx[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        T s = lu[i];
+#pragma unroll
+        for (int q = 0; q < NX; ++q)
+            if (M::fu_nz(q, i)) s = fma_(fu[q][i], Vx[q], s);
+        Qu[i] = s;
+    }
+    // Vxx + lm I (ilqr.py:95)
+#pragma unroll
+    for (int i = 0; i < NX; ++i) Vxx[i][i] += p.lm;
+    // Mx = fx' Vxx ; Qxx = l_xx + Mx fx (ilqr.py:96)
+    T Mx[NX][NX], Qxx[NX][NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            T s = T(0);
+            bool have = false;
+#pragma unroll
+            for (int q = 0; q < NX; ++q)
+                if (M::fx_nz(q, i)) {
+                    s = !have ? (M::fx_one(q, i) ? Vxx[q][j] : fx[q][i] * Vxx[q][j])
+                              : (M::fx_one(q, i) ? s + Vxx[q][j] : fma_(fx[q][i], Vxx[q][j], s));
+                    have = true;
+                }
+            Mx[i][j] = s;
+        }
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            T s = lxx[i][j];
+#pragma unroll
+            for (int q = 0; q < NX; ++q)
+                if (M::fx_nz(q, j)) s = M::fx_one(q, j) ? s + Mx[i][q] : fma_(Mx[i][q], fx[q][j], s);
+            Qxx[i][j] = s;
+        }
+    // Mu = fu' Vxx ; Quu = l_uu + Mu fu ; Qux = Mu fx (ilqr.py:97-98)
+    T Mu[NU][NX], Quu[NU][NU], Qux[NU][NX];
+#pragma unroll
+    for (int i = 0; i < NU; ++i)
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            T s = T(0);
+            bool have = false;
+#pragma unroll
+            for (int q = 0; q < NX; ++q)
+                if (M::fu_nz(q, i)) {
+                    s = !have ? fu[q][i] * Vxx[q][j] : fma_(fu[q][i], Vxx[q][j], s);
+                    have = true;
+                }
+            Mu[i][j] = s;
+        }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            T s = (DIAG && i != j) ? T(0) : p.R2[i * NU + j];
+#pragma unroll
+            for (int q = 0; q < NX; ++q)
+                if (M::fu_nz(q, j)) s = fma_(Mu[i][q], fu[q][j], s);
+            Quu[i][j] = s;
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            T s = T(0);
+            bool have = false;
+#pragma unroll
+            for (int q = 0; q < NX; ++q)
+                if (M::fx_nz(q, j)) {
+                    s = !have ? (M::fx_one(q, j) ? Mu[i][q] : Mu[i][q] * fx[q][j])
+                              : (M::fx_one(q, j) ? s + Mu[i][q] : fma_(Mu[i][q], fx[q][j], s));
+                    have = true;
+                }
+            Qux[i][j] = s;
+        }
+    }
+    // k = -Quu^-1 Qu ; K = -Quu^-1 Qux (ilqr.py:99-101)
+    T rhs[NU][NX + 1];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        rhs[i][0] = -Qu[i];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) rhs[i][j + 1] = -Qux[i][j];
+    }
+    int st = solve_quu<T, NU, NX + 1>(Quu, rhs);
+    if (CONSTR & 1) {
+        // cilqr.py:112-134.  min 1/2 du'Quu du + (2 Qu)'du, lo-u <= du <= hi-u.  The result is
+        // used only when every multiplier exceeds lambda in magnitude, i.e. the minimiser is a
+        // corner of the box with all bounds strictly active; a corner c is the minimiser iff
+        // y = -(Quu c + 2Qu) is < 0 on lower and > 0 on upper bounds.
+        bool found = false;
+        T du[NU];
+#pragma unroll
+        for (int mask = 0; mask < (1 << NU); ++mask) {
+            T c[NU];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) c[j] = ((mask >> j) & 1) ? (p.hi[j] - u[j]) : (p.lo[j] - u[j]);
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                T g = T(2) * Qu[i];
+#pragma unroll
+                for (int j = 0; j < NU; ++j) g = fma_(Quu[i][j], c[j], g);
+                T y = -g;
+                ok = ok && (((mask >> i) & 1) ? (y > p.lambda) : (y < -p.lambda));
+            }
+            if (ok && !found) {
+                found = true;
+#pragma unroll
+                for (int j = 0; j < NU; ++j) du[j] = c[j];
+            }
+        }
+        if (found) {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                rhs[i][0] = du[i];
+#pragma unroll
+                for (int j = 0; j < NX; ++j) rhs[i][j + 1] = T(0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        kt[i] = rhs[i][0];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) Kt[i][j] = rhs[i][j + 1];
+    }
+    // Vx = Qx + K' Qu ; Vxx = Qxx + K' Qux (ilqr.py:104-105; not symmetrised)
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        T s = Qx[i];
+#pragma unroll
+        for (int q = 0; q < NU; ++q) s = fma_(Kt[q][i], Qu[q], s);
+        Vx[i] = s;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            T w = Qxx[i][j];
+#pragma unroll
+            for (int q = 0; q < NU; ++q) w = fma_(Kt[q][i], Qux[q][j], w);
+            Vxx[i][j] = w;
+        }
+    }
+    return st;
+}
+
+template <typename T, int NX, int NU> struct StepRow { // the rows of one time step the backward pass reads
+    T x[NX], u[NU], xr[NX], cx, cy, rad;
+};
+
+template <typename T, class M, bool DIAG, int CONSTR, int PF>
+__global__ __launch_bounds__(64) void backward_kernel(Params<T, M::NX, M::NU> p) {
+    constexpr int NX = M::NX, NU = M::NU;
+    const int b0 = blockIdx.x * 64 + threadIdx.x;
+    const bool valid = b0 < p.B;
+    const int b = valid ? b0 : p.B - 1;
+    const bool active = valid && p.converged[b] == 0;
+    if (__ballot(active) == 0ull) return;
+    const int T1 = p.N - 1;
+    constexpr bool BARRIER_ = (CONSTR & 2) != 0;
+    const int tile = b >> 6, ln = b & 63;
+    const T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
+    const T *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
+    const T *Ut = tile_ptr(p.U, tile, (p.N - 1) * NU, ln);
+    const T *Cp = BARRIER_ ? tile_ptr(p.centers, tile, p.N * 2, ln) : nullptr;
+    const T *Dp = BARRIER_ ? tile_ptr(p.radius, tile, p.N, ln) : nullptr;
+    T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
+    T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+
+    auto load_row = [&](int t, StepRow<T, NX, NU> &r) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            r.x[i] = Xt[(t * NX + i) * TILE];
+            r.xr[i] = Rt[(t * NX + i) * TILE];
+        }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) r.u[i] = Ut[(t * NU + i) * TILE];
+        if (CONSTR & 2) {
+            r.cx = Cp[(t * 2 + 0) * TILE];
+            r.cy = Cp[(t * 2 + 1) * TILE];
+            r.rad = Dp[t * TILE];
+        } else {
+            r.cx = r.cy = r.rad = T(0);
+        }
+    };
+
+    // terminal condition (ilqr.py:79-82)
+    T Vx[NX], Vxx[NX][NX];
+    {
+        T x[NX], e[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            x[i] = Xt[(T1 * NX + i) * TILE];
+            e[i] = x[i] - Rt[(T1 * NX + i) * TILE];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            if (DIAG) {
+                Vx[i] = p.Qf2[i * NX + i] * e[i];
+            } else {
+                T s = p.Qf2[i * NX] * e[0];
+#pragma unroll
+                for (int j = 1; j < NX; ++j) s = fma_(p.Qf2[i * NX + j], e[j], s);
+                Vx[i] = s;
+            }
+#pragma unroll
+            for (int j = 0; j < NX; ++j) Vxx[i][j] = (DIAG && i != j) ? T(0) : p.Qf2[i * NX + j];
+        }
+        if (CONSTR & 2)
+            barrier_terms<T, NX, true>(p, x, Cp[(T1 * 2 + 0) * TILE], Cp[(T1 * 2 + 1) * TILE],
+                                       Dp[T1 * TILE], Vx, Vxx);
+    }
+
+    StepRow<T, NX, NU> ring[PF];
+#pragma unroll
+    for (int s = 0; s < PF; ++s)
+        if (T1 - 1 - s >= 0) load_row(T1 - 1 - s, ring[s]);
+    int status = 0;
+    for (int tb = T1 - 1; tb >= 0; tb -= PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            const int t = tb - s;
+            if (t < 0) break;
+            StepRow<T, NX, NU> cur = ring[s];
+            if (t - PF >= 0) load_row(t - PF, ring[s]);
+            T Kt[NU][NX], kt[NU];
+            status |= riccati_step<T, M, DIAG, CONSTR>(p, t, cur.x, cur.u, cur.xr, cur.cx, cur.cy, cur.rad, Vx, Vxx, Kt, kt);
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    kp[(t * NU + i) * TILE] = kt[i];
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) Kp[((t * NU + i) * NX + j) * TILE] = Kt[i][j];
+                }
+            }
+        }
+    }
+    if (active && status != 0 && p.status) p.status[b] |= status;
+}
+
+// ---------------------------------------------------------------- rollout step
+// u_new = (u_prev + alpha k) + K (x_new - x_prev), clamped (ilqr.py:56-61).
+template <typename T, class M, class P>
+__device__ __forceinline__ void control_update(const P &p, T alpha, const T (&x)[M::NX], const T (&xp)[M::NX], const T (&up)[M::NU],
+                                               const T (&Kt)[M::NU][M::NX], const T (&kt)[M::NU], T (&un)[M::NU]) {
+    constexpr int NX = M::NX, NU = M::NU;
+    T dx[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dx[i] = x[i] - xp[i];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        T fb = Kt[i][0] * dx[0];
+#pragma unroll
+        for (int j = 1; j < NX; ++j) fb = fma_(Kt[i][j], dx[j], fb);
+        T v = fma_(alpha, kt[i], up[i]) + fb;
+        if (p.control_limited) {
+            v = (p.lo[i] > v) ? p.lo[i] : v; // max(v, lo) with Python's NaN behaviour
+            v = (p.hi[i] < v) ? p.hi[i] : v; // min(v, hi)
+        }
+        un[i] = v;
+    }
+}
+
+template <typename T, int NX, int NU> struct FwdRow { // rows of one step shared by all step sizes of a problem
+    T K[NU][NX], k[NU], xp[NX], up[NU], xr[NX], cx, cy, rad;
+};
+
+// ---------------------------------------------------------------- evaluate
+// L lanes per problem x A step sizes per lane = L*A candidates per round;
+// rounds continue (in increasing index order, so the largest improving step
+// wins exactly as in the serial search) until every problem of the wave has a
+// winner or the candidates are exhausted.
+template <typename T, class M, bool DIAG, bool BARRIER, int L, int A>
+__global__ __launch_bounds__(256) void evaluate_kernel(Params<T, M::NX, M::NU> p) {
+    constexpr int NX = M::NX, NU = M::NU;
+    constexpr int PPW = 64 / L; // problems per wave
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int pl = lane / L, al = lane % L;
+    const int b0 = wave * PPW + pl;
+    const bool valid = b0 < p.B;
+    const int b = valid ? b0 : p.B - 1;
+    const bool active = valid && p.converged[b] == 0;
+    if (__ballot(active) == 0ull) return;
+    const int T1 = p.N - 1;
+    const T Jcur = p.J[b];
+    constexpr bool BARRIER_ = BARRIER;
+    const int tile = b >> 6, ln = b & 63;
+    const T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
+    const T *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
+    const T *Ut = tile_ptr(p.U, tile, (p.N - 1) * NU, ln);
+    const T *Cp = BARRIER_ ? tile_ptr(p.centers, tile, p.N * 2, ln) : nullptr;
+    const T *Dp = BARRIER_ ? tile_ptr(p.radius, tile, p.N, ln) : nullptr;
+    const T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
+    const T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+
+    auto load_row = [&](int t, FwdRow<T, NX, NU> &r) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            r.k[i] = kp[(t * NU + i) * TILE];
+            r.up[i] = Ut[(t * NU + i) * TILE];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) r.K[i][j] = Kp[((t * NU + i) * NX + j) * TILE];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            r.xp[i] = Xt[(t * NX + i) * TILE];
+            r.xr[i] = Rt[(t * NX + i) * TILE];
+        }
+        if (BARRIER) {
+            r.cx = Cp[(t * 2 + 0) * TILE];
+            r.cy = Cp[(t * 2 + 1) * TILE];
+            r.rad = Dp[t * TILE];
+        } else {
+            r.cx = r.cy = r.rad = T(0);
+        }
+    };
+
+    int best = 0x7fffffff;
+    T best_cost = T(0);
+    T dlx[NX], dlxx[NX][NX];
+    for (int base = 0; base < p.n_alphas; base += L * A) {
+        T x[A][NX], cost[A], alpha[A];
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            alpha[j] = pow2_neg<T>(base + al * A + j);
+            cost[j] = T(0);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[j][i] = Xt[i * TILE];
+        }
+        FwdRow<T, NX, NU> nxt;
+        load_row(0, nxt);
+        for (int t = 0; t < T1; ++t) {
+            FwdRow<T, NX, NU> r = nxt;
+            if (t + 1 < T1) load_row(t + 1, nxt);
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                T e[NX], un[NU], xn[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) e[i] = x[j][i] - r.xr[i];
+                control_update<T, M>(p, alpha[j], x[j], r.xp, r.up, r.K, r.k, un);
+                T stage = quad_<T, NX, DIAG>(p.Q, e) + quad_<T, NU, DIAG>(p.R, un);
+                if (BARRIER && t > 0) stage += barrier_terms<T, NX, false>(p, x[j], r.cx, r.cy, r.rad, dlx, dlxx);
+                cost[j] += stage;
+                M::step(p, t, x[j], un, xn);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) x[j][i] = xn[i];
+            }
+        }
+        // terminal term (ilqr.py:44-45)
+        T xr[NX], cx = T(0), cy = T(0), rad = T(0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xr[i] = Rt[(T1 * NX + i) * TILE];
+        if (BARRIER) {
+            cx = Cp[(T1 * 2 + 0) * TILE];
+            cy = Cp[(T1 * 2 + 1) * TILE];
+            rad = Dp[T1 * TILE];
+        }
+        int cand = 0x7fffffff;
+        T cand_cost = T(0);
+#pragma unroll
+        for (int j = A - 1; j >= 0; --j) {
+            T e[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) e[i] = x[j][i] - xr[i];
+            T term = quad_<T, NX, DIAG>(p.Qf, e);
+            if (BARRIER) term += barrier_terms<T, NX, false>(p, x[j], cx, cy, rad, dlx, dlxx);
+            T c = cost[j] + term;
+            const int a = base + al * A + j;
+            if (a < p.n_alphas && c < Jcur) { // strict test of ilqr.py:65; NaN never passes
+                cand = a;
+                cand_cost = c;
+            }
+        }
+        // lowest candidate index among the L lanes of the problem
+#pragma unroll
+        for (int off = 1; off < L; off <<= 1) {
+            int oc = __shfl_xor(cand, off);
+            T ocost = __shfl_xor(cand_cost, off);
+            if (oc < cand) {
+                cand = oc;
+                cand_cost = ocost;
+            }
+        }
+        if (best == 0x7fffffff && cand != 0x7fffffff) {
+            best = cand;
+            best_cost = cand_cost;
+        }
+        if (__ballot(active && best == 0x7fffffff) == 0ull) break;
+    }
+    if (active && al == 0) {
+        p.alpha_idx[b] = (best == 0x7fffffff) ? -1 : best;
+        p.Jtry[b] = best_cost;
+    }
+}
+
+// ---------------------------------------------------------------- commit
+// One lane per problem.  Rolls the accepted step size out once more and
+// overwrites X and U in place (each lane reads a row before it overwrites it);
+// problems without an accepted step keep their trajectory and become converged
+// (ilqr.py:69-73).
+template <typename T, class M, int PF>
+__global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, int it) {
+    constexpr int NX = M::NX, NU = M::NU;
+    const int b0 = blockIdx.x * 64 + threadIdx.x;
+    const bool valid = b0 < p.B;
+    const int b = valid ? b0 : p.B - 1;
+    const bool active = valid && p.converged[b] == 0;
+    if (__ballot(active) == 0ull) return;
+    const size_t B = p.B;
+    const int T1 = p.N - 1;
+    const int tile = b >> 6, ln = b & 63;
+    T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
+    T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
+    const T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
+    const T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    const int idx = p.alpha_idx[b];
+    const bool roll = active && idx >= 0;
+    if (active) {
+        p.iters[b] += 1;
+        T Jn = roll ? p.Jtry[b] : p.J[b];
+        if (roll) {
+            p.J[b] = Jn;
+            if (p.status && !(fabs_(Jn) < inf_<T>())) p.status[b] |= ILQR_STATUS_NONFINITE_;
+        } else {
+            p.converged[b] = 1;
+        }
+        if (it < p.hist_cap) {
+            if (p.hist_cost) p.hist_cost[size_t(it) * B + b] = Jn;
+            if (p.hist_alpha) p.hist_alpha[size_t(it) * B + b] = idx;
+        }
+    }
+    if (__ballot(roll) == 0ull) return;
+    const T alpha = pow2_neg<T>(roll ? idx : 0);
+
+    struct Row {
+        T K[NU][NX], k[NU], xp[NX], up[NU];
+    };
+    auto load_row = [&](int t, Row &r) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            r.k[i] = kp[(t * NU + i) * TILE];
+            r.up[i] = Ut[(t * NU + i) * TILE];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) r.K[i][j] = Kp[((t * NU + i) * NX + j) * TILE];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) r.xp[i] = Xt[(t * NX + i) * TILE];
+    };
+    T x[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = Xt[i * TILE];
+    Row ring[PF];
+#pragma unroll
+    for (int s = 0; s < PF; ++s)
+        if (s < T1) load_row(s, ring[s]);
+    for (int tb = 0; tb < T1; tb += PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            const int t = tb + s;
+            if (t >= T1) break;
+            Row r = ring[s];
+            // the row of step t+PF is read here, before any store to it below (stores reach
+            // at most row t+1 <= t+PF)
+            if (t + PF < T1) load_row(t + PF, ring[s]);
+            T un[NU], xn[NX];
+            control_update<T, M>(p, alpha, x, r.xp, r.up, r.K, r.k, un);
+            M::step(p, t, x, un, xn);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = xn[i];
+            if (roll) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) Ut[(t * NU + i) * TILE] = un[i];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) Xt[((t + 1) * NX + i) * TILE] = xn[i];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- layout conversion
+// reference layout [B][rows] (one problem contiguous) <-> tiled device layout
+// [ceil(B/64)][rows][64].  One workgroup moves a 64-problem x 64-row patch through LDS so
+// both the global read and the global write are contiguous.
+template <typename E, bool TO_TILED>
+__global__ __launch_bounds__(256) void relayout_kernel(const E *__restrict__ src, E *__restrict__ dst, int B, int rows) {
+    __shared__ E patch[64][65];
+    const int tile = blockIdx.y, r0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const size_t tbase = (size_t)tile * rows * TILE;
+    if (TO_TILED) {
+        for (int i = ty; i < 64; i += 4) { // problem i of the tile, row r0 + tx
+            const int b = tile * 64 + i, r = r0 + tx;
+            patch[i][tx] = (b < B && r < rows) ? src[(size_t)b * rows + r] : E(0);
+        }
+        __syncthreads();
+        for (int i = ty; i < 64; i += 4) { // row r0 + i, lane tx
+            const int r = r0 + i;
+            if (r < rows) dst[tbase + (size_t)r * TILE + tx] = patch[tx][i];
+        }
+    } else {
+        for (int i = ty; i < 64; i += 4) {
+            const int r = r0 + i;
+            if (r < rows) patch[i][tx] = src[tbase + (size_t)r * TILE + tx];
+        }
+        __syncthreads();
+        for (int i = ty; i < 64; i += 4) {
+            const int b = tile * 64 + i, r = r0 + tx;
+            if (b < B && r < rows) dst[(size_t)b * rows + r] = patch[tx][i];
+        }
+    }
+}
+
+} // namespace ilqr

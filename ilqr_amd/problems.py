@@ -1,0 +1,239 @@
+"""Seeded problem constructions for the batched iLQR path.
+
+Two families:
+
+* ``demo_*``: the three problem constructions of the reference demos
+  (``ilqr_demo.py:9-49`` Car, ``:89-135`` CarAcceleration, ``:170-192``
+  DubinsCar and ``cilqr.py:154-196``), with the module-level ``random`` stream
+  seeded explicitly so they are reproducible.
+* ``car_batch`` / ``caracc_batch`` / ``dubins_batch``: the batched synthetic
+  generator.  Problem ``b`` draws everything from
+  ``numpy.random.Generator(PCG64(seed0 + b))`` so its data do not depend on the
+  batch size or on how the batch is sharded over GPUs.
+
+Everything here is host-side numpy in the reference's array layout
+(``target_states (B, N, n)``, ``inputs (B, N-1, m)``, ``x0 (B, n)``).
+"""
+import random as _pyrandom
+
+import numpy as np
+
+CAR_Q = np.diag([50.0, 50.0, 1000.0, 0.0])
+CAR_R = np.diag([3000.0, 1000.0])
+CAR_LIMITS = ([-1.5, -0.3], [1.5, 0.3])
+CARACC_Q = np.diag([50.0, 50.0, 1000.0, 1000.0, 0.0])
+CARACC_R = np.diag([3000.0, 1000.0])
+CARACC_LIMITS = ([-6.0, -0.2], [6.0, 0.2])
+DUBINS_Q = 100.0 * np.diag([1.0, 1.0, 1.0])
+DUBINS_R = np.diag([10.0, 100.0])
+DUBINS_LIMITS = ([0.0, -0.2], [2.0, 0.2])
+
+
+def demo_car(horizon=120, seed=0, noise_xy=3.0, noise_th=0.5):
+    """Problem of ``ilqr_demo.py:10-45`` (noise_xy=3) or ``cilqr.py:155-192``
+    (noise_xy=15) with ``random.seed(seed)``.  Returns (noisy_targets,
+    init_inputs, ref_vel)."""
+    rnd = _pyrandom.Random(seed)
+    target = np.zeros((horizon, 4))
+    noisy = np.zeros((horizon, 4))
+    ref_vel = np.zeros(horizon)
+    dt, curv, a, v_max = 0.2, 0.1, 1.5, 11
+    for i in range(40, horizon):
+        if ref_vel[i - 1] > v_max:
+            a = 0
+        ref_vel[i] = ref_vel[i - 1] + a * dt
+    for i in range(1, horizon):
+        target[i, 0] = target[i - 1, 0] + np.cos(target[i - 1, 3]) * dt * ref_vel[i - 1]
+        target[i, 1] = target[i - 1, 1] + np.sin(target[i - 1, 3]) * dt * ref_vel[i - 1]
+        target[i, 2] = ref_vel[i]
+        target[i, 3] = target[i - 1, 3] + curv * dt
+        noisy[i, 0] = target[i, 0] + rnd.uniform(0, noise_xy)
+        noisy[i, 1] = target[i, 1] + rnd.uniform(0, noise_xy)
+        noisy[i, 2] = ref_vel[i]
+        noisy[i, 3] = target[i, 3] + rnd.uniform(0, noise_th)
+    init_inputs = np.zeros((horizon - 1, 2))
+    for i in range(1, horizon):
+        init_inputs[i - 1, 0] = (noisy[i, 2] - noisy[i - 1, 2]) / dt
+        init_inputs[i - 1, 1] = (noisy[i, 3] - noisy[i - 1, 3]) / dt
+    return noisy, init_inputs, ref_vel
+
+
+def demo_caracc(horizon=100, seed=0):
+    """Problem of ``ilqr_demo.py:89-131`` with ``random.seed(seed)``."""
+    rnd = _pyrandom.Random(seed)
+    target = np.zeros((horizon, 5))
+    noisy = np.zeros((horizon, 5))
+    ref_vel = np.zeros(horizon)
+    ref_acc = np.zeros(horizon)
+    dt, curv, a, v_max = 0.2, 0.1, 1.5, 11
+    for i in range(40, horizon):
+        if ref_vel[i - 1] > v_max:
+            a = 0
+        ref_acc[i] = a
+        ref_vel[i] = ref_vel[i - 1] + a * dt
+    for i in range(1, horizon):
+        target[i, 0] = target[i - 1, 0] + np.cos(target[i - 1, 4]) * dt * ref_vel[i - 1]
+        target[i, 1] = target[i - 1, 1] + np.sin(target[i - 1, 4]) * dt * ref_vel[i - 1]
+        target[i, 2] = ref_vel[i]
+        target[i, 3] = ref_acc[i]
+        target[i, 4] = target[i - 1, 4] + curv * dt
+        noisy[i, 0] = target[i, 0] + rnd.uniform(0, 1)
+        noisy[i, 1] = target[i, 1] + rnd.uniform(0, 1)
+        noisy[i, 2] = target[i, 2]
+        noisy[i, 3] = target[i, 3]
+        noisy[i, 4] = target[i, 4] + rnd.uniform(0, 0.1)
+    init_inputs = np.zeros((horizon - 1, 2))
+    for i in range(1, horizon):
+        init_inputs[i - 1, 0] = (noisy[i, 3] - noisy[i - 1, 3]) / dt
+        init_inputs[i - 1, 1] = (noisy[i, 4] - noisy[i - 1, 4]) / dt
+    return noisy, init_inputs
+
+
+def demo_dubins(horizon=200, seed=0):
+    """Problem of ``ilqr_demo.py:170-185`` with ``random.seed(seed)``; the demo
+    leaves the inputs at zero."""
+    rnd = _pyrandom.Random(seed)
+    target = np.zeros((horizon, 3))
+    noisy = np.zeros((horizon, 3))
+    dt, v, curv = 0.2, 1.0, 0.1
+    for i in range(1, horizon):
+        target[i, 0] = target[i - 1, 0] + np.cos(target[i - 1, 2]) * v * dt
+        target[i, 1] = target[i - 1, 1] + np.sin(target[i - 1, 2]) * v * dt
+        target[i, 2] = target[i - 1, 2] + v * curv * dt
+        noisy[i, 0] = target[i, 0] + rnd.uniform(0, 1)
+        noisy[i, 1] = target[i, 1] + rnd.uniform(0, 1)
+        noisy[i, 2] = target[i, 2] + rnd.uniform(0, 1)
+    return noisy, np.zeros((horizon - 1, 2))
+
+
+def _one_car(b, seed0, N, dt, noise_xy, noise_th, ramp_start):
+    rng = np.random.Generator(np.random.PCG64(seed0 + b))
+    curv = rng.uniform(-0.15, 0.15)
+    a = rng.uniform(0.5, 2.0)
+    v_max = rng.uniform(6.0, 12.0)
+    x0 = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(0, 2),
+                   rng.uniform(-np.pi, np.pi)])
+    noise = rng.uniform(0.0, 1.0, size=(N - 1, 3))
+    ref_vel = np.zeros(N)
+    acc = a
+    for i in range(ramp_start, N):
+        if ref_vel[i - 1] > v_max:
+            acc = 0.0
+        ref_vel[i] = ref_vel[i - 1] + acc * dt
+    # heading is an arithmetic progression; positions are its prefix sums
+    theta = x0[3] + curv * dt * np.arange(N)
+    target = np.zeros((N, 4))
+    target[0, 0], target[0, 1] = x0[0], x0[1]
+    target[1:, 0] = x0[0] + np.cumsum(np.cos(theta[:-1]) * dt * ref_vel[:-1])
+    target[1:, 1] = x0[1] + np.cumsum(np.sin(theta[:-1]) * dt * ref_vel[:-1])
+    target[:, 2] = ref_vel
+    target[:, 3] = theta
+    noisy = target.copy()
+    noisy[1:, 0] += noise_xy * noise[:, 0]
+    noisy[1:, 1] += noise_xy * noise[:, 1]
+    noisy[1:, 3] += noise_th * noise[:, 2]
+    init_inputs = np.empty((N - 1, 2))
+    init_inputs[:, 0] = (noisy[1:, 2] - noisy[:-1, 2]) / dt
+    init_inputs[:, 1] = (noisy[1:, 3] - noisy[:-1, 3]) / dt
+    return noisy, init_inputs, x0
+
+
+def car_batch(B, N=200, seed0=1234, first=0, dt=0.2, noise_xy=3.0, noise_th=0.5,
+              ramp_start=40):
+    """Batched synthetic Car problems ``first .. first+B-1``.
+
+    Per problem: curvature U(-0.15,0.15), acceleration U(0.5,2), speed cap
+    U(6,12), initial state (U(-5,5), U(-5,5), U(0,2), U(-pi,pi)); the
+    reference arc of ``ilqr_demo.py:25-35`` starts at the initial pose; noise
+    and finite-difference initial inputs as ``ilqr_demo.py:36-45``.
+
+    ``init_states`` is the reference's all-zero initial state guess
+    (``ilqr.py:31-32``) expressed in the problem's own frame: the initial pose
+    (px0, py0, theta0) at every step with zero speed, and ``x0`` itself at
+    step 0.  It is NOT a rollout of ``init_inputs`` (the reference never
+    rolls its initial guess out either).
+
+    Returns dict(target_states (B,N,4), init_inputs (B,N-1,2), x0 (B,4),
+    init_states (B,N,4)).
+    """
+    tg = np.empty((B, N, 4))
+    ui = np.empty((B, N - 1, 2))
+    x0 = np.empty((B, 4))
+    for j in range(B):
+        tg[j], ui[j], x0[j] = _one_car(first + j, seed0, N, dt, noise_xy, noise_th,
+                                       ramp_start)
+    st = np.repeat(x0[:, None, :], N, axis=1)
+    st[:, 1:, 2] = 0.0
+    return {"target_states": tg, "init_inputs": ui, "x0": x0, "init_states": st}
+
+
+def caracc_batch(B, N=100, seed0=4321, first=0, dt=0.2):
+    """Batched CarAcceleration problems in the style of ``ilqr_demo.py:89-131``
+    with per-problem curvature/acceleration/speed cap and initial state."""
+    tg = np.zeros((B, N, 5))
+    ui = np.zeros((B, N - 1, 2))
+    x0 = np.zeros((B, 5))
+    for j in range(B):
+        rng = np.random.Generator(np.random.PCG64(seed0 + first + j))
+        curv = rng.uniform(-0.15, 0.15)
+        a = rng.uniform(0.5, 2.0)
+        v_max = rng.uniform(6.0, 12.0)
+        x0[j] = [rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(0, 2), 0.0,
+                 rng.uniform(-np.pi, np.pi)]
+        noise = rng.uniform(0.0, 1.0, size=(N - 1, 3))
+        ref_vel = np.zeros(N)
+        ref_acc = np.zeros(N)
+        acc = a
+        for i in range(40, N):
+            if ref_vel[i - 1] > v_max:
+                acc = 0.0
+            ref_acc[i] = acc
+            ref_vel[i] = ref_vel[i - 1] + acc * dt
+        theta = x0[j, 4] + curv * dt * np.arange(N)
+        t = tg[j]
+        t[0, 0], t[0, 1] = x0[j, 0], x0[j, 1]
+        t[1:, 0] = x0[j, 0] + np.cumsum(np.cos(theta[:-1]) * dt * ref_vel[:-1])
+        t[1:, 1] = x0[j, 1] + np.cumsum(np.sin(theta[:-1]) * dt * ref_vel[:-1])
+        t[:, 2] = ref_vel
+        t[:, 3] = ref_acc
+        t[:, 4] = theta
+        t[1:, 0] += noise[:, 0]
+        t[1:, 1] += noise[:, 1]
+        t[1:, 4] += 0.1 * noise[:, 2]
+        ui[j, :, 0] = (t[1:, 3] - t[:-1, 3]) / dt
+        ui[j, :, 1] = (t[1:, 4] - t[:-1, 4]) / dt
+    st = np.repeat(x0[:, None, :], N, axis=1)
+    st[:, 1:, 2] = 0.0
+    return {"target_states": tg, "init_inputs": ui, "x0": x0, "init_states": st}
+
+
+def dubins_batch(B, N=200, seed0=9876, first=0, dt=0.2):
+    """Batched DubinsCar problems in the style of ``ilqr_demo.py:170-185``."""
+    tg = np.zeros((B, N, 3))
+    ui = np.zeros((B, N - 1, 2))
+    x0 = np.zeros((B, 3))
+    for j in range(B):
+        rng = np.random.Generator(np.random.PCG64(seed0 + first + j))
+        curv = rng.uniform(-0.15, 0.15)
+        v = rng.uniform(0.5, 1.5)
+        x0[j] = [rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(-np.pi, np.pi)]
+        noise = rng.uniform(0.0, 1.0, size=(N - 1, 3))
+        theta = x0[j, 2] + v * curv * dt * np.arange(N)
+        t = tg[j]
+        t[0, 0], t[0, 1] = x0[j, 0], x0[j, 1]
+        t[1:, 0] = x0[j, 0] + np.cumsum(np.cos(theta[:-1]) * v * dt)
+        t[1:, 1] = x0[j, 1] + np.cumsum(np.sin(theta[:-1]) * v * dt)
+        t[:, 2] = theta
+        t[1:] += noise
+    st = np.repeat(x0[:, None, :], N, axis=1)
+    return {"target_states": tg, "init_inputs": ui, "x0": x0, "init_states": st}
+
+
+def bubbles_for(target_states, radius=4.0, vel_bounds=(-1.0, 14.0)):
+    """Keep-in discs centred on the target positions, as ``sqp_demo.py:40-53``
+    populates ``BubbleConstraint.setup(centers, radius, vel_bounds)``.
+
+    Returns (centers (B,N,2), radius (B,N), vel_bounds (2,))."""
+    centers = np.ascontiguousarray(target_states[..., :2])
+    rad = np.full(target_states.shape[:-1], float(radius))
+    return centers, rad, np.asarray(vel_bounds, dtype=float)

@@ -1,0 +1,166 @@
+/*
+ * ilqr_amd C ABI: batched iLQR / constrained iLQR on AMD MI355X (gfx950).
+ *
+ * The reference (zetian/ilqr) is pure Python and exposes no FFI; its boundary is
+ * the object protocol of ilqr.py:17 (constructor), ilqr.py:107 (__call__) and
+ * the attributes a caller assigns or reads (ilqr_demo.py:47-58).  The entry
+ * points below are what a binding for that path needs: every function cites
+ * the reference code it replaces.  All pointers are plain device pointers owned
+ * by the caller; no torch types appear; nothing here allocates or frees device
+ * memory, and nothing synchronises the stream (ilqr_active_count excepted).
+ *
+ * Device layout is structure-of-arrays with the batch index innermost, in tiles
+ * of 64 problems (one gfx950 wavefront): an array with `rows` values per problem
+ * is stored as [ceil(B/64)][rows][64]; element (b, r) lives at
+ * (b/64)*rows*64 + r*64 + b%64.  Buffers are sized for ceil(B/64)*64 problems.
+ *   X      rows = N*n        states            (ilqr.py:31  self.states)
+ *   U      rows = (N-1)*m    inputs            (ilqr.py:33  self.inputs)
+ *   Xref   rows = N*n        target_states     (ilqr.py:18)
+ *   K      rows = (N-1)*m*n  feedback gains    (ilqr.py:78  self.K)
+ *   k      rows = (N-1)*m    feed-forward      (ilqr.py:77  self.k)
+ *   centers rows = N*2, radius rows = N        (constraints.py:15-18, per problem)
+ * Per-problem scalars are plain arrays of B elements:
+ *   J      [B]            min_cost          (ilqr.py:29)
+ *   converged, iters, alpha_idx, status [B] int32
+ * ilqr_to_tiled / ilqr_from_tiled convert from / to the reference's layout
+ * ([B][rows], one problem contiguous).
+ * Element type is double (ILQR_F64) or float (ILQR_F32) as set in the descriptor.
+ *
+ * Return value: 0 on success, a negative ilqr_status otherwise; never throws.
+ * Per-problem numerical events are reported in the device array `status`, not
+ * in the return code.  A handle is not thread-safe; use one handle per stream.
+ */
+#ifndef ILQR_AMD_H
+#define ILQR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ILQR_MAX_N 12
+#define ILQR_MAX_M 4
+
+typedef enum ilqr_status {
+    ILQR_OK = 0,
+    ILQR_ERR_INVALID = -1,     /* bad descriptor field or NULL pointer */
+    ILQR_ERR_UNSUPPORTED = -2, /* combination not built (model/dtype/shape) */
+    ILQR_ERR_NOT_BOUND = -3,   /* a required buffer was not bound */
+    ILQR_ERR_HIP = -4          /* a HIP runtime call failed (see ilqr_last_hip_error) */
+} ilqr_status;
+
+/* device dynamics: systems.py:27-57 / :59-90 / :92-121; LTV has no reference counterpart */
+typedef enum ilqr_model {
+    ILQR_MODEL_CAR = 0,
+    ILQR_MODEL_CARACC = 1,
+    ILQR_MODEL_DUBINS = 2,
+    ILQR_MODEL_LTV = 3
+} ilqr_model;
+
+typedef enum ilqr_dtype { ILQR_F64 = 0, ILQR_F32 = 1 } ilqr_dtype;
+
+/* bit flags for ilqr_desc.constraint_mode */
+#define ILQR_CONSTR_NONE 0
+#define ILQR_CONSTR_BOXQP 1   /* cilqr.py:112-134: per-step box QP on the control step */
+#define ILQR_CONSTR_BARRIER 2 /* relaxed log barrier on constraints.py:20-26 (no reference solver uses it) */
+
+/* per-problem bits in the device array `status` */
+#define ILQR_STATUS_NONPD 1   /* a Quu was not positive definite; solved by pivoted LU like numpy.linalg.inv */
+#define ILQR_STATUS_SINGULAR 2 /* a Quu was exactly singular (ilqr.py:99 would raise LinAlgError) */
+#define ILQR_STATUS_NONFINITE 4 /* the accepted cost is not finite */
+
+typedef struct ilqr_desc {
+    int32_t B;               /* problems in this handle (this GPU's shard) */
+    int32_t N;               /* horizon = target_states.shape[0] (ilqr.py:19) */
+    int32_t n, m;            /* sys.state_size / sys.control_size (ilqr.py:23-24) */
+    int32_t model;           /* ilqr_model */
+    int32_t dtype;           /* ilqr_dtype */
+    int32_t control_limited; /* system.control_limited: clamp inputs in the rollout (ilqr.py:58-61) */
+    int32_t constraint_mode; /* ILQR_CONSTR_* flags */
+    int32_t n_alphas;        /* line-search candidates 2^0..2^-(n_alphas-1); 0 = derive from alpha_floor */
+    int32_t lanes_per_problem; /* forward mapping: lanes of a wave that share one problem (1,2,4,8,16); 0 = auto */
+    int32_t alphas_per_lane;   /* step sizes each lane rolls out per round (1,2,4,8,16); 0 = auto */
+    int32_t reserved0;
+    double dt;               /* system.dt (systems.py:30); the solver's own dt argument is unused (ilqr.py:20) */
+    double lm_parameter;     /* ilqr.py:30, added to Vxx (ilqr.py:95) */
+    double alpha_floor;      /* 1e-4 (ilqr.py:71) or alpha_terminal (cilqr.py:41) */
+    double input_limit_lambda; /* cilqr.py:40 */
+    double barrier_mu;       /* barrier weight */
+    double barrier_delta;    /* barrier relaxation width (quadratic extension below it) */
+    double vel_bounds[2];    /* constraints.py:18 */
+    double Q[ILQR_MAX_N * ILQR_MAX_N];  /* row-major n x n (ilqr.py:25) */
+    double R[ILQR_MAX_M * ILQR_MAX_M];  /* row-major m x m (ilqr.py:26) */
+    double Qf[ILQR_MAX_N * ILQR_MAX_N]; /* row-major n x n (ilqr.py:27) */
+    double lo[ILQR_MAX_M], hi[ILQR_MAX_M]; /* systems.py:21-24 */
+} ilqr_desc;
+
+/* Device buffers, caller-owned.  Optional ones may be NULL. */
+typedef struct ilqr_buffers {
+    void *X, *U;             /* in/out */
+    const void *Xref;        /* in */
+    void *K, *k;             /* out (rewritten by every backward pass, ilqr.py:77-78) */
+    void *J;                 /* in/out: min_cost */
+    int32_t *converged;      /* in/out: ilqr.py:21 self.converge, per problem */
+    int32_t *iters;          /* in/out: backward+forward pairs executed */
+    int32_t *alpha_idx;      /* out: accepted step index of the last forward pass, -1 = none */
+    int32_t *status;         /* in/out: ILQR_STATUS_* bits, or NULL */
+    void *work;              /* scratch of ilqr_workspace_bytes() */
+    const void *centers, *radius; /* barrier mode only */
+    const void *ltv_A, *ltv_B;    /* ILQR_MODEL_LTV only: [N-1][n][n], [N-1][n][m], shared by the batch */
+    void *hist_cost;         /* optional [hist_capacity][B]: min_cost after each iteration */
+    int32_t *hist_alpha;     /* optional [hist_capacity][B]: accepted step index after each iteration */
+    int32_t hist_capacity;
+    int32_t reserved0;
+} ilqr_buffers;
+
+typedef struct ilqr_handle ilqr_handle;
+
+/* replaces iterative_LQR.__init__ (ilqr.py:17-34, cilqr.py:25-45): captures sizes,
+ * weights, limits and solver parameters.  Host-only; no device work. */
+int ilqr_create(const ilqr_desc *desc, ilqr_handle **out);
+void ilqr_destroy(ilqr_handle *h);
+
+/* bytes of the `work` scratch buffer this handle needs */
+size_t ilqr_workspace_bytes(const ilqr_handle *h);
+/* number of line-search candidates the handle uses (15 for ilqr.py, 8 for cilqr.py defaults) */
+int32_t ilqr_num_alphas(const ilqr_handle *h);
+
+/* attaches device buffers; replaces the attribute assignments of ilqr_demo.py:47-49 */
+int ilqr_bind(ilqr_handle *h, const ilqr_buffers *bufs);
+
+/* J[b] = cost of the current (X, U) for every problem: ilqr.py:108 / :36-46 */
+int ilqr_initial_cost(ilqr_handle *h, void *stream);
+/* one backward pass for every non-converged problem: ilqr.py:76-105, cilqr.py:87-139 */
+int ilqr_backward(ilqr_handle *h, void *stream);
+/* one forward pass (line search) for every non-converged problem: ilqr.py:48-74.
+ * `iteration` indexes the history buffers (ignored if none are bound).
+ * ilqr_forward = ilqr_forward_evaluate (all step sizes rolled out in parallel,
+ * winner selected) followed by ilqr_forward_commit (winner written in place). */
+int ilqr_forward(ilqr_handle *h, int32_t iteration, void *stream);
+int ilqr_forward_evaluate(ilqr_handle *h, void *stream);
+int ilqr_forward_commit(ilqr_handle *h, int32_t iteration, void *stream);
+/* iterative_LQR.__call__ (ilqr.py:107-114): initial cost, then max_iter x
+ * (backward, forward); converged problems are skipped on the device. */
+int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream);
+/* number of problems with converged == 0; synchronises `stream` */
+int ilqr_active_count(ilqr_handle *h, void *stream, int32_t *out);
+
+/* layout helpers: reference layout [B][rows] (what numpy holds, e.g. states (B, N, n)
+ * flattened) <-> tiled device layout [ceil(B/64)][rows][64]; elem_bytes 4 or 8; both
+ * pointers are device pointers; padding lanes of the last tile are zero-filled */
+int ilqr_to_tiled(const void *aos, void *tiled, int32_t B, int32_t rows, int32_t elem_bytes, void *stream);
+int ilqr_from_tiled(const void *tiled, void *aos, int32_t B, int32_t rows, int32_t elem_bytes, void *stream);
+
+const char *ilqr_strerror(int code);
+/* hipError_t of the last failing HIP call on this thread (0 if none) */
+int ilqr_last_hip_error(void);
+/* ABI guards: sizeof(ilqr_desc) / sizeof(ilqr_buffers) as compiled into the library */
+int32_t ilqr_desc_size(void);
+int32_t ilqr_buffers_size(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ILQR_AMD_H */
