@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched iLQR hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One *step* = one complete batched solve (``iterative_LQR.__call__``: initial cost, then up to
+30 backward/forward iterations per problem until its ``converge`` flag) of B Car problems with
+horizon N=200 in fp64, the configuration BASELINE.json's metric is quoted on.  Inputs are
+resident in HBM when the timed region starts; every step restores the initial guess with a
+device-to-device copy (inside the timed region) and solves again.  With N GPUs every rank
+solves its own B problems (weak scaling, no communication on the solve path); the reported
+value is the whole-job rate.
+
+Prints ONE JSON line on rank 0 with the metric, a ``roofline`` object for the dominant kernel
+(per-launch HIP-event timings taken inside the timed region) and, at N=1, a ``cpu_baseline``
+object: the C oracle (a port of the reference's per-problem loop) timed on the host cores on
+a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def algorithmic_bytes(N, n, m, w=8):
+    """Per problem and iteration, fp64: what each phase must read and write at least.
+    backward: read X, U, Xref, write K, k.  evaluate: read K, k, X, U, Xref (all step sizes
+    share one read).  commit: write the winning X, U."""
+    T = N - 1
+    return {
+        "backward": w * (2 * N * n + T * m + T * m * n + T * m),
+        "evaluate": w * (T * m * n + T * m + 2 * N * n + T * m),
+        "commit": w * (N * n + T * m),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=65536, help="problems per GPU")
+    ap.add_argument("--horizon", type=int, default=200)
+    ap.add_argument("--strong", action="store_true", help="split --batch over the GPUs instead of per-GPU")
+    ap.add_argument("--mapping", default="auto", help="forward mapping L,A (lanes per problem, step sizes per lane)")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=65536, help="upper bound on problems in the CPU baseline sample")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ilqr_amd import dist as idist, problems, systems
+    from ilqr_amd.ilqr import iterative_LQR
+
+    rank, world, local = idist.env_rank_world()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+            sys.exit(2)
+    torch.cuda.set_device(local)
+    idist.init_process_group("nccl" if world > 1 else None)
+
+    N = args.horizon
+    if args.strong:
+        first, B = idist.shard_range(args.batch, rank, world)
+        B_total = args.batch
+    else:
+        B, first, B_total = args.batch, rank * args.batch, args.batch * world
+    car = systems.Car()
+    car.set_dt(0.2)
+    car.set_cost(problems.CAR_Q.copy(), problems.CAR_R.copy())
+    car.set_control_limit(*problems.CAR_LIMITS)
+    p = problems.car_batch(B, N, first=first)
+
+    kw = {}
+    if args.mapping != "auto":
+        L, A = (int(v) for v in args.mapping.split(","))
+        kw = dict(lanes_per_problem=L, alphas_per_lane=A)
+    np_dtype = np.float64 if args.dtype == "f64" else np.float32
+    opt = iterative_LQR(car, p["target_states"], car.dt, history=True, dtype=np_dtype, **kw)
+    opt.inputs, opt.states = p["init_inputs"], p["init_states"]
+    dev = opt.upload()
+    X0, U0 = dev.X.clone(), dev.U.clone()
+    max_iter = opt.maxIter
+
+    def reset():
+        dev.X.copy_(X0)
+        dev.U.copy_(U0)
+        dev.converged.zero_()
+        dev.iters.zero_()
+        dev.hist_alpha.fill_(-2)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def solve_step(events=None):
+        """The phases of ilqr_solve, launched one by one so that events can bracket them."""
+        reset()
+        dev.initial_cost()
+        for it in range(max_iter):
+            if events is not None:
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                e[0].record()
+                dev.backward()
+                e[1].record()
+                dev.forward_evaluate()
+                e[2].record()
+                dev.forward_commit(it)
+                e[3].record()
+                events.append(e)
+            else:
+                dev.backward()
+                dev.forward(it)
+
+    for _ in range(args.warmup):
+        solve_step()
+    barrier()
+    events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solve_step(events)
+    barrier()
+    dt_local = time.perf_counter() - t0
+    tmax = torch.tensor([dt_local], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    # per-problem outcome of the last step (identical every step: same inputs)
+    iters = dev.iters.cpu().numpy()
+    conv = dev.converged.cpu().numpy()
+    ha = dev.hist_alpha.cpu().numpy()                     # [max_iter][B]
+    active = (ha != -2).sum(axis=1).astype(np.int64)       # problems that executed iteration it
+    accepted = (ha >= 0).sum(axis=1).astype(np.int64)
+    iter_sum = torch.tensor([float(iters.sum()), float(conv.sum())], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(iter_sum)
+
+    # per-kernel timings from the events of the timed region (this rank)
+    kt = {"backward": [], "evaluate": [], "commit": []}
+    for e in events:
+        kt["backward"].append(e[0].elapsed_time(e[1]))
+        kt["evaluate"].append(e[1].elapsed_time(e[2]))
+        kt["commit"].append(e[2].elapsed_time(e[3]))
+    ab = algorithmic_bytes(N, 4, 2, 8 if args.dtype == "f64" else 4)
+    units = {"backward": active, "evaluate": active, "commit": accepted}
+    kernels = {}
+    for name, ms in kt.items():
+        ms = np.array(ms).reshape(args.steps, max_iter)
+        live = units[name] > 0
+        total_ms = ms[:, live].sum()
+        total_bytes = float(args.steps) * float((units[name][live] * ab[name]).sum())
+        kernels[name] = {
+            "launches": int(live.sum()) * args.steps,
+            "avg_ms": float(total_ms / max(1, live.sum() * args.steps)),
+            "total_ms": float(total_ms),
+            "achieved_GBs": float(total_bytes / (total_ms * 1e-3) / 1e9) if total_ms > 0 else 0.0,
+            "bytes_per_problem": ab[name],
+        }
+    dominant = max(kernels, key=lambda k: kernels[k]["total_ms"])
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dominant, {}).get("bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = None
+    if rank == 0:
+        solves = float(B_total) * args.steps
+        out = {
+            "metric": "batched iLQR solves/sec (B=65536, N=200)",
+            "value": solves / elapsed,
+            "unit": "solves/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong" if args.strong else "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic (seeded Car tracking problems, ilqr_amd.problems.car_batch)",
+            "config": {"workload": f"Car n=4 m=2, N={N}, B={B} problems per GPU, maxIter=30, 15 parallel step sizes",
+                       "batch_per_gpu": B, "batch_total": B_total, "horizon": N,
+                       "forward_mapping": f"L={dev.desc.lanes_per_problem or 'auto'},A={dev.desc.alphas_per_lane or 'auto'}"},
+            "mean_iterations_per_solve": float(iter_sum[0].item()) / B_total,
+            "converged_fraction": float(iter_sum[1].item()) / B_total,
+            "executed_iterations_per_step": float(iter_sum[0].item()),
+            "roofline": {
+                "kernel": dominant, "bound": "hbm",
+                "achieved": kernels[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": kernels[dominant]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
+                "avg_launch_ms": kernels[dominant]["avg_ms"],
+                "bytes_per_problem_per_launch": ab[dominant],
+            },
+            "kernels": kernels,
+            "solve_achieved_GBs": float(args.steps * (active * (ab["backward"] + ab["evaluate"]) + accepted * ab["commit"]).sum()
+                                        / elapsed / 1e9) * (world if not args.strong else 1),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(car, p, N, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(car, p, N, sample):
+    """The C oracle (a scalar per-problem port of ilqr.py) on the first `sample` problems of
+    the same workload, OpenMP over problems on the host cores this process may use."""
+    from oracle import oracle
+    oracle.lib()
+    cores = min(16, len(os.sched_getaffinity(0)))
+    d = oracle.make_desc(car, N)
+    tg = np.ascontiguousarray(p["target_states"][:64])
+    # scale the sample so the run takes roughly 30 core-seconds of CPU work in total
+    st, ui = p["init_states"][:64].copy(), p["init_inputs"][:64].copy()
+    t0 = time.perf_counter()
+    oracle.solve_batch(d, tg[:64], st, ui, nthreads=cores, history=False)
+    probe = time.perf_counter() - t0
+    per_problem_core_s = probe * cores / 64.0
+    sample = int(max(64, min(sample, p["target_states"].shape[0], 30.0 / max(per_problem_core_s, 1e-9))))
+    tg = np.ascontiguousarray(p["target_states"][:sample])
+    st, ui = p["init_states"][:sample].copy(), p["init_inputs"][:sample].copy()
+    t0 = time.perf_counter()
+    r = oracle.solve_batch(d, tg[:sample], st, ui, nthreads=cores, history=False)
+    el = time.perf_counter() - t0
+    return {"value": sample / el, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": f"first {sample} problems of the same batch, C oracle (scalar fp64 port of ilqr.py), "
+                      f"OpenMP over problems, {el:.1f} s wall, mean {float(r['iters'].mean()):.1f} iterations"}
+
+
+if __name__ == "__main__":
+    main()

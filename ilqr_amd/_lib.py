@@ -83,6 +83,10 @@ def lib():
             raise IlqrError(
                 f"{LIB_PATH} not found: the HIP library is not built "
                 "(run __graft_entry__.build() or make -C ilqr_amd/csrc); there is no CPU fallback")
+        # PyTorch-ROCm ships its own copy of the HIP runtime; load it first so that this
+        # library binds to the same runtime instance as the tensors that carry its buffers
+        # (two runtimes in one process do not share devices, streams or allocations).
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)

