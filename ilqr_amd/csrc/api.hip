@@ -88,14 +88,19 @@ int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
     if (na <= 0 || na > 64) return ILQR_ERR_INVALID;
     int L = d.lanes_per_problem, A = d.alphas_per_lane;
     if (L == 0 && A == 0) {
-        L = 16;
-        A = 1;
+        // All 16 candidates of a round are rolled out at once; how they are spread over lanes is a
+        // pure speed choice.  Few lanes per problem means more independent rollouts per lane
+        // (instruction-level parallelism, shared row loads); many lanes per problem means more
+        // waves, which small batches need to occupy the 1024 SIMDs.  Aim at >= 2048 waves.
+        L = 2;
+        while (L < 16 && (long)d.B * L < 131072L) L *= 2;
+        A = 16 / L;
     } else if (L == 0 || A == 0) {
         return ILQR_ERR_INVALID;
     }
     {
         const int key = L * 100 + A;
-        const int ok[] = {1601, 802, 404, 116, 801, 401, 104, 204};
+        const int ok[] = {1601, 802, 404, 208, 116, 801, 401, 104, 204};
         bool found = false;
         for (int v : ok) found = found || (v == key);
         if (!found) return ILQR_ERR_UNSUPPORTED;

@@ -130,6 +130,7 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
         case 802: return eval_la<BARRIER, 8, 2>(c, s);
         case 404: return eval_la<BARRIER, 4, 4>(c, s);
         case 116: return eval_la<BARRIER, 1, 16>(c, s);
+        case 208: return eval_la<BARRIER, 2, 8>(c, s);
         case 801: return eval_la<BARRIER, 8, 1>(c, s);
         case 401: return eval_la<BARRIER, 4, 1>(c, s);
         case 104: return eval_la<BARRIER, 1, 4>(c, s);

@@ -32,7 +32,44 @@ template <typename T> __device__ __forceinline__ T fma_(T a, T b, T c);
 template <> __device__ __forceinline__ double fma_<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
 template <> __device__ __forceinline__ float fma_<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-__device__ __forceinline__ void sincos_(double x, double &s, double &c) { sincos(x, &s, &c); }
+// fp64 sine and cosine of one angle, <= 1 ulp.  Fast path for |x| < 2^20: Cody-Waite reduction
+// by pi/2 split into three doubles (the products are exact inside the fused multiply-adds),
+// then the fdlibm minimax kernels on [-pi/4, pi/4] (S1..S6, C1..C6 of __kernel_sin/__kernel_cos,
+// Sun Microsystems, freely distributable) and a quadrant swap.  Larger arguments, infinities
+// and NaNs take the library routine (Payne-Hanek) on a cold path.
+__device__ __forceinline__ void sincos_(double x, double &s, double &c) {
+    if (__builtin_expect(!(__builtin_fabs(x) < 1048576.0), 0)) {
+        sincos(x, &s, &c);
+        return;
+    }
+    const double q = __builtin_rint(x * 6.36619772367581382433e-01);
+    double r = __builtin_fma(q, -1.57079632679489655800e+00, x);
+    r = __builtin_fma(q, -6.12323399573676603587e-17, r);
+    r = __builtin_fma(q, 1.49738490485916983528e-33, r);
+    const int n = (int)q;
+    const double z = r * r;
+    // sin(r) = r + r^3 (S1 + z (S2 + ...))
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    const double sr = __builtin_fma(z * r, ps, r);
+    // cos(r) = 1 - z/2 + z^2 (C1 + z (C2 + ...)), with the rounding error of 1 - z/2 recovered
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double cr = w + (((1.0 - w) - hz) + z * (z * pc));
+    // quadrant: n mod 4 = 0: (s, c) ; 1: (c, -s) ; 2: (-s, -c) ; 3: (-c, s)
+    const double s0 = (n & 1) ? cr : sr;
+    const double c0 = (n & 1) ? sr : cr;
+    s = (n & 2) ? -s0 : s0;
+    c = ((n + 1) & 2) ? -c0 : c0;
+}
 __device__ __forceinline__ void sincos_(float x, float &s, float &c) { sincosf(x, &s, &c); }
 __device__ __forceinline__ double log_(double x) { return log(x); }
 __device__ __forceinline__ float log_(float x) { return logf(x); }
@@ -54,6 +91,9 @@ template <> __device__ __forceinline__ float inf_<float>() { return __builtin_hu
 // single base pointer plus small constant offsets, and every access is a full
 // 512-byte (fp64) row.
 constexpr int TILE = 64;
+#ifndef EVAL_MIN_WAVES
+#define EVAL_MIN_WAVES 1
+#endif
 template <typename T> __device__ __forceinline__ T *tile_ptr(T *base, int tile, int rows, int lane) {
     return base + (size_t)tile * (size_t)rows * TILE + lane;
 }
@@ -699,7 +739,7 @@ template <typename T, int NX, int NU> struct FwdRow { // rows of one step shared
 // wins exactly as in the serial search) until every problem of the wave has a
 // winner or the candidates are exhausted.
 template <typename T, class M, bool DIAG, bool BARRIER, int L, int A>
-__global__ __launch_bounds__(256) void evaluate_kernel(Params<T, M::NX, M::NU> p) {
+__global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T, M::NX, M::NU> p) {
     constexpr int NX = M::NX, NU = M::NU;
     constexpr int PPW = 64 / L; // problems per wave
     const int lane = threadIdx.x & 63;

@@ -67,7 +67,7 @@ def main():
     for B in (4096, 65536):
         t0 = time.time(); p = problems.car_batch(B, 200); t1 = time.time()
         car = cf.demo_car_system()
-        for L, A in ((16, 1), (4, 4), (1, 16), (4, 1), (8, 1), (1, 4), (8, 2), (2, 4)):
+        for L, A in ((16, 1), (8, 2), (4, 4), (2, 8), (1, 16), (2, 4)):
             opt = iterative_LQR(car, p["target_states"], car.dt, lanes_per_problem=L, alphas_per_lane=A)
             opt.inputs = p["init_inputs"].copy(); opt.states = p["init_states"].copy()
             dev = opt.upload(); torch.cuda.synchronize()
