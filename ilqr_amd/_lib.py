@@ -14,7 +14,8 @@ STATUS_NONPD, STATUS_SINGULAR, STATUS_NONFINITE = 1, 2, 4
 TILE = 64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libilqr_amd.so")
+# ILQR_AMD_LIB selects another build of the same library (used to A/B compiler options)
+LIB_PATH = os.environ.get("ILQR_AMD_LIB") or os.path.join(_HERE, "libilqr_amd.so")
 
 
 class IlqrError(RuntimeError):
@@ -27,7 +28,7 @@ class Desc(C.Structure):
         ("model", C.c_int32), ("dtype", C.c_int32), ("control_limited", C.c_int32),
         ("constraint_mode", C.c_int32), ("n_alphas", C.c_int32),
         ("lanes_per_problem", C.c_int32), ("alphas_per_lane", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("n_streams", C.c_int32),
         ("dt", C.c_double), ("lm_parameter", C.c_double), ("alpha_floor", C.c_double),
         ("input_limit_lambda", C.c_double), ("barrier_mu", C.c_double),
         ("barrier_delta", C.c_double), ("vel_bounds", C.c_double * 2),

@@ -9,9 +9,17 @@
 
 using namespace ilqr;
 
+constexpr int MAX_PARTS = 8;
+
 struct ilqr_handle {
     HostCtx ctx;
     const ModelOps *ops = nullptr;
+    // ilqr_solve may split the batch into parts that run on streams of their own, so that one
+    // part's arithmetic-bound line search overlaps another part's bandwidth-bound passes
+    int n_parts = 1;
+    bool streams_ready = false;
+    hipStream_t part_stream[MAX_PARTS] = {};
+    hipEvent_t fork_event = nullptr, join_event[MAX_PARTS] = {};
 };
 
 static thread_local int g_last_hip_error = 0;
@@ -113,20 +121,46 @@ int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
     h->ctx.n_alphas = na;
     h->ctx.L = L;
     h->ctx.A = A;
+    h->ctx.first = 0;
+    h->ctx.count = d.B;
     h->ops = ops;
+    {
+        int parts = d.n_streams;
+        if (parts < 0 || parts > MAX_PARTS) {
+            delete h;
+            return ILQR_ERR_INVALID;
+        }
+        const int tiles = (d.B + TILE - 1) / TILE;
+        if (parts == 0) parts = 1;
+        if (parts > tiles) parts = tiles;
+        h->n_parts = parts;
+    }
     *out = h;
     return ILQR_OK;
 }
 
-void ilqr_destroy(ilqr_handle *h) { delete h; }
+void ilqr_destroy(ilqr_handle *h) {
+    if (!h) return;
+    if (h->streams_ready) {
+        for (int s = 0; s < h->n_parts; ++s) {
+            if (h->part_stream[s]) (void)hipStreamDestroy(h->part_stream[s]);
+            if (h->join_event[s]) (void)hipEventDestroy(h->join_event[s]);
+        }
+        if (h->fork_event) (void)hipEventDestroy(h->fork_event);
+    }
+    delete h;
+}
 
 static size_t jtry_bytes(const ilqr_handle *h) {
     const size_t e = h->ctx.d.dtype == ILQR_F64 ? 8 : 4;
     return ((size_t)h->ctx.d.B * e + 255) & ~(size_t)255;
 }
 
-// layout of `work`: [ trial cost of the accepted step size, per problem | 256 B of counters ]
-size_t ilqr_workspace_bytes(const ilqr_handle *h) { return h ? jtry_bytes(h) + 256 : 0; }
+static size_t flag_bytes(const ilqr_handle *h) { return ((size_t)h->ctx.d.B * 4 + 255) & ~(size_t)255; }
+
+// layout of `work`: [ trial cost of the accepted step size, per problem | slow-trigonometry flag,
+// per problem (int32) | 256 B of counters ]
+size_t ilqr_workspace_bytes(const ilqr_handle *h) { return h ? jtry_bytes(h) + flag_bytes(h) + 256 : 0; }
 
 int32_t ilqr_num_alphas(const ilqr_handle *h) { return h ? h->ctx.n_alphas : 0; }
 
@@ -172,13 +206,61 @@ int ilqr_forward(ilqr_handle *h, int32_t iteration, void *stream) {
     return ilqr_forward_commit(h, iteration, stream);
 }
 
+static int solve_part(ilqr_handle *h, const HostCtx &c, int max_iter, hipStream_t s) {
+    int rc = hip_rc(h->ops->cost(c, 0, s));
+    for (int it = 0; it < max_iter && rc == ILQR_OK; ++it) {
+        rc = hip_rc(h->ops->backward(c, 0, s));
+        if (rc == ILQR_OK) rc = hip_rc(h->ops->evaluate(c, 0, s));
+        if (rc == ILQR_OK) rc = hip_rc(h->ops->commit(c, it, s));
+    }
+    return rc;
+}
+
 int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream) {
     REQUIRE_BOUND(h);
     if (max_iter < 0) return ILQR_ERR_INVALID;
-    int rc = ilqr_initial_cost(h, stream);
-    for (int it = 0; it < max_iter && rc == ILQR_OK; ++it) {
-        rc = ilqr_backward(h, stream);
-        if (rc == ILQR_OK) rc = ilqr_forward(h, it, stream);
+    hipStream_t user = (hipStream_t)stream;
+    if (h->n_parts <= 1) return solve_part(h, h->ctx, max_iter, user);
+    // fork: every part waits for the caller's stream, runs its whole solve on a stream of its
+    // own (parts are disjoint tile ranges, so they never touch the same memory), and the
+    // caller's stream waits for all parts.  No host synchronisation.
+    if (!h->streams_ready) {
+        hipError_t e = hipEventCreateWithFlags(&h->fork_event, hipEventDisableTiming);
+        for (int s = 0; s < h->n_parts && e == hipSuccess; ++s) {
+            e = hipStreamCreateWithFlags(&h->part_stream[s], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&h->join_event[s], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) return hip_rc(e);
+        h->streams_ready = true;
+    }
+    hipError_t e = hipEventRecord(h->fork_event, user);
+    if (e != hipSuccess) return hip_rc(e);
+    const int tiles = (h->ctx.d.B + TILE - 1) / TILE;
+    int rc = ILQR_OK;
+    // launch order: iteration-major across parts, so that the parts advance together and the
+    // hardware queues always hold kernels of different phases
+    HostCtx part[MAX_PARTS];
+    for (int s = 0; s < h->n_parts; ++s) {
+        part[s] = h->ctx;
+        const int t0 = (int)((long)tiles * s / h->n_parts), t1 = (int)((long)tiles * (s + 1) / h->n_parts);
+        part[s].first = t0 * TILE;
+        const int end = t1 * TILE < h->ctx.d.B ? t1 * TILE : h->ctx.d.B;
+        part[s].count = end - part[s].first;
+        e = hipStreamWaitEvent(h->part_stream[s], h->fork_event, 0);
+        if (e != hipSuccess) return hip_rc(e);
+        rc = hip_rc(h->ops->cost(part[s], 0, h->part_stream[s]));
+        if (rc != ILQR_OK) return rc;
+    }
+    for (int it = 0; it < max_iter && rc == ILQR_OK; ++it)
+        for (int s = 0; s < h->n_parts && rc == ILQR_OK; ++s) {
+            rc = hip_rc(h->ops->backward(part[s], 0, h->part_stream[s]));
+            if (rc == ILQR_OK) rc = hip_rc(h->ops->evaluate(part[s], 0, h->part_stream[s]));
+            if (rc == ILQR_OK) rc = hip_rc(h->ops->commit(part[s], it, h->part_stream[s]));
+        }
+    for (int s = 0; s < h->n_parts; ++s) {
+        e = hipEventRecord(h->join_event[s], h->part_stream[s]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(user, h->join_event[s], 0);
+        if (e != hipSuccess && rc == ILQR_OK) rc = hip_rc(e);
     }
     return rc;
 }
@@ -196,7 +278,7 @@ int ilqr_active_count(ilqr_handle *h, void *stream, int32_t *out) {
     REQUIRE_BOUND(h);
     if (!out) return ILQR_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    int32_t *counter = (int32_t *)((char *)h->ctx.b.work + jtry_bytes(h));
+    int32_t *counter = (int32_t *)((char *)h->ctx.b.work + jtry_bytes(h) + flag_bytes(h));
     hipError_t e = hipMemsetAsync(counter, 0, sizeof(int32_t), s);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(count_active_kernel, dim3((h->ctx.d.B + 255) / 256), dim3(256), 0, s, h->ctx.b.converged, h->ctx.d.B, counter);

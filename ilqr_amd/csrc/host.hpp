@@ -4,6 +4,8 @@
 #include "../../include/ilqr_amd.h"
 #include "kernels.hpp"
 
+#include <limits>
+
 namespace ilqr {
 
 struct HostCtx {
@@ -13,6 +15,9 @@ struct HostCtx {
     bool diag = false;   // Q, R, Qf all diagonal
     int n_alphas = 0;
     int L = 16, A = 1;   // forward mapping
+    // a launch may cover only the problems [first, first + count) of the bound batch
+    // (first is a multiple of 64 so that the part starts on a tile boundary)
+    int first = 0, count = 0;
 };
 
 typedef hipError_t (*launch_fn)(const HostCtx &, int it, hipStream_t);
@@ -29,30 +34,39 @@ template <typename T, int NX, int NU> static Params<T, NX, NU> make_params(const
     Params<T, NX, NU> p;
     const ilqr_desc &d = c.d;
     const ilqr_buffers &b = c.b;
-    p.X = (T *)b.X;
-    p.U = (T *)b.U;
-    p.Xref = (const T *)b.Xref;
-    p.K = (T *)b.K;
-    p.k = (T *)b.k;
-    p.J = (T *)b.J;
-    p.Jtry = (T *)b.work;
-    p.converged = b.converged;
-    p.iters = b.iters;
-    p.alpha_idx = b.alpha_idx;
-    p.status = b.status;
-    p.centers = (const T *)b.centers;
-    p.radius = (const T *)b.radius;
+    const int N = d.N, T1 = d.N - 1;
+    const size_t tile0 = (size_t)(c.first / TILE), f = (size_t)c.first;
+    auto tiled = [&](const void *base, int rows) -> T * {
+        return base ? (T *)base + tile0 * (size_t)rows * TILE : nullptr;
+    };
+    auto flat = [&](auto *base) { return base ? base + f : base; };
+    p.X = tiled(b.X, N * NX);
+    p.U = tiled(b.U, T1 * NU);
+    p.Xref = tiled(b.Xref, N * NX);
+    p.K = tiled(b.K, T1 * NU * NX);
+    p.k = tiled(b.k, T1 * NU);
+    p.J = flat((T *)b.J);
+    p.Jtry = flat((T *)b.work);
+    {
+        const size_t e = sizeof(T);
+        const size_t jtry_bytes = ((size_t)d.B * e + 255) & ~(size_t)255;
+        p.slow_trig = flat((int32_t *)((char *)b.work + jtry_bytes));
+    }
+    p.converged = flat(b.converged);
+    p.iters = flat(b.iters);
+    p.alpha_idx = flat(b.alpha_idx);
+    p.status = flat(b.status);
+    p.centers = tiled(b.centers, N * 2);
+    p.radius = tiled(b.radius, N);
     p.ltvA = (const T *)b.ltv_A;
     p.ltvB = (const T *)b.ltv_B;
-    p.hist_cost = (T *)b.hist_cost;
-    p.hist_alpha = b.hist_alpha;
+    p.hist_cost = flat((T *)b.hist_cost);
+    p.hist_alpha = flat(b.hist_alpha);
     p.hist_cap = (b.hist_cost || b.hist_alpha) ? b.hist_capacity : 0;
-    p.B = d.B;
+    p.hist_stride = d.B;
+    p.B = c.count;
     p.N = d.N;
     p.n_alphas = c.n_alphas;
-    p.control_limited = d.control_limited;
-    p.boxqp = (d.constraint_mode & ILQR_CONSTR_BOXQP) ? 1 : 0;
-    p.barrier = (d.constraint_mode & ILQR_CONSTR_BARRIER) ? 1 : 0;
     p.dt = (T)d.dt;
     p.lm = (T)d.lm_parameter;
     p.lambda = (T)d.input_limit_lambda;
@@ -70,16 +84,26 @@ template <typename T, int NX, int NU> static Params<T, NX, NU> make_params(const
         p.R[i] = (T)d.R[i];
         p.R2[i] = (T)(2.0 * d.R[i]);
     }
-    for (int i = 0; i < NU; ++i) {
-        p.lo[i] = (T)d.lo[i];
-        p.hi[i] = (T)d.hi[i];
+    for (int i = 0; i < NU; ++i) { // rollout clamp (ilqr.py:58-61); the identity without limits
+        p.lo[i] = d.control_limited ? (T)d.lo[i] : -std::numeric_limits<T>::infinity();
+        p.hi[i] = d.control_limited ? (T)d.hi[i] : std::numeric_limits<T>::infinity();
+    }
+    for (int i = 0; i < NU; ++i) { // box of the backward-pass QP (cilqr.py:116-117)
+        p.qlo[i] = (T)d.lo[i];
+        p.qhi[i] = (T)d.hi[i];
     }
     return p;
 }
 
 // prefetch depth (time steps in flight per lane) of the lane-per-problem kernels
-constexpr int PF_BACKWARD = 3;
-constexpr int PF_COMMIT = 2;
+#ifndef ILQR_PF_BACKWARD
+#define ILQR_PF_BACKWARD 3
+#endif
+#ifndef ILQR_PF_COMMIT
+#define ILQR_PF_COMMIT 2
+#endif
+constexpr int PF_BACKWARD = ILQR_PF_BACKWARD;
+constexpr int PF_COMMIT = ILQR_PF_COMMIT;
 
 template <typename T, template <typename> class MT, bool DIAG> struct Launch {
     using M = MT<T>;
@@ -89,7 +113,7 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
 
     static hipError_t cost(const HostCtx &c, int, hipStream_t s) {
         auto p = make_params<T, NX, NU>(c);
-        const dim3 grid((c.d.B + 63) / 64), block(64);
+        const dim3 grid((c.count + 63) / 64), block(64);
         if constexpr (M::HAS_BARRIER) {
             if (barrier_on(c)) {
                 hipLaunchKernelGGL((cost_kernel<T, M, DIAG, true>), grid, block, 0, s, p);
@@ -102,7 +126,7 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
     }
     template <int CONSTR> static hipError_t backward_c(const HostCtx &c, hipStream_t s) {
         auto p = make_params<T, NX, NU>(c);
-        hipLaunchKernelGGL((backward_kernel<T, M, DIAG, CONSTR, PF_BACKWARD>), dim3((c.d.B + 63) / 64), dim3(64), 0, s, p);
+        hipLaunchKernelGGL((backward_kernel<T, M, DIAG, CONSTR, PF_BACKWARD>), dim3((c.count + 63) / 64), dim3(64), 0, s, p);
         return hipGetLastError();
     }
     static hipError_t backward(const HostCtx &c, int, hipStream_t s) {
@@ -118,7 +142,7 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
     template <bool BARRIER, int L, int A> static hipError_t eval_la(const HostCtx &c, hipStream_t s) {
         auto p = make_params<T, NX, NU>(c);
         const int ppw = 64 / L;                        // problems per wave
-        const long waves = ((long)c.d.B + ppw - 1) / ppw;
+        const long waves = ((long)c.count + ppw - 1) / ppw;
         const int blocks = (int)((waves + 3) / 4);     // 4 waves per workgroup
         hipLaunchKernelGGL((evaluate_kernel<T, M, DIAG, BARRIER, L, A>), dim3(blocks), dim3(256), 0, s, p);
         return hipGetLastError();
@@ -147,7 +171,7 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
     }
     static hipError_t commit(const HostCtx &c, int it, hipStream_t s) {
         auto p = make_params<T, NX, NU>(c);
-        hipLaunchKernelGGL((commit_kernel<T, M, PF_COMMIT>), dim3((c.d.B + 63) / 64), dim3(64), 0, s, p, it);
+        hipLaunchKernelGGL((commit_kernel<T, M, PF_COMMIT>), dim3((c.count + 63) / 64), dim3(64), 0, s, p, it);
         return hipGetLastError();
     }
     static const ModelOps *table() {

@@ -32,16 +32,19 @@ template <typename T> __device__ __forceinline__ T fma_(T a, T b, T c);
 template <> __device__ __forceinline__ double fma_<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
 template <> __device__ __forceinline__ float fma_<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-// fp64 sine and cosine of one angle, <= 1 ulp.  Fast path for |x| < 2^20: Cody-Waite reduction
-// by pi/2 split into three doubles (the products are exact inside the fused multiply-adds),
-// then the fdlibm minimax kernels on [-pi/4, pi/4] (S1..S6, C1..C6 of __kernel_sin/__kernel_cos,
-// Sun Microsystems, freely distributable) and a quadrant swap.  Larger arguments, infinities
-// and NaNs take the library routine (Payne-Hanek) on a cold path.
-__device__ __forceinline__ void sincos_(double x, double &s, double &c) {
-    if (__builtin_expect(!(__builtin_fabs(x) < 1048576.0), 0)) {
+// fp64 sine and cosine of one angle, <= 1 ulp.  FAST: Cody-Waite reduction by pi/2 split into
+// three doubles (the products are exact inside the fused multiply-adds), then the fdlibm
+// minimax kernels on [-pi/4, pi/4] (S1..S6, C1..C6 of __kernel_sin/__kernel_cos, Sun
+// Microsystems, freely distributable) and a quadrant swap.  The fast form is branch-free so
+// that a whole time step stays one basic block the scheduler can interleave; it is valid for
+// |x| < 2^20 and reports anything else (larger arguments, infinities, NaN) in `bad`.  A kernel
+// that sees `bad` anywhere in a wave redoes its work with FAST = false, the library routine.
+template <bool FAST> __device__ __forceinline__ void sincos_(double x, double &s, double &c, bool &bad) {
+    if (!FAST) {
         sincos(x, &s, &c);
         return;
     }
+    bad = bad || !(__builtin_fabs(x) < 1048576.0);
     const double q = __builtin_rint(x * 6.36619772367581382433e-01);
     double r = __builtin_fma(q, -1.57079632679489655800e+00, x);
     r = __builtin_fma(q, -6.12323399573676603587e-17, r);
@@ -70,7 +73,7 @@ __device__ __forceinline__ void sincos_(double x, double &s, double &c) {
     s = (n & 2) ? -s0 : s0;
     c = ((n + 1) & 2) ? -c0 : c0;
 }
-__device__ __forceinline__ void sincos_(float x, float &s, float &c) { sincosf(x, &s, &c); }
+template <bool FAST> __device__ __forceinline__ void sincos_(float x, float &s, float &c, bool &) { sincosf(x, &s, &c); }
 __device__ __forceinline__ double log_(double x) { return log(x); }
 __device__ __forceinline__ float log_(float x) { return logf(x); }
 __device__ __forceinline__ double fabs_(double x) { return fabs(x); }
@@ -107,18 +110,20 @@ template <typename T, int NX, int NU> struct Params {
     T *K, *k;
     T *J, *Jtry;
     int32_t *converged, *iters, *alpha_idx, *status;
+    int32_t *slow_trig; // per problem: the evaluate kernel needed the library sine/cosine
     const T *centers, *radius;
     const T *ltvA, *ltvB;
     T *hist_cost;
     int32_t *hist_alpha;
     int32_t hist_cap;
+    int32_t hist_stride; // problems per history row (the whole batch, also when this launch covers a part)
     int32_t B, N;
     int32_t n_alphas;
-    int32_t control_limited, boxqp, barrier;
     T dt, lm, lambda, mu, delta, vlo, vhi;
     T Q[NX * NX], R[NU * NU], Qf[NX * NX];
     T Q2[NX * NX], R2[NU * NU], Qf2[NX * NX];
-    T lo[NU], hi[NU];
+    T lo[NU], hi[NU];   // rollout clamp; -inf/+inf when the system has no control limits
+    T qlo[NU], qhi[NU]; // box of the per-step QP of the constrained solver
 };
 
 // ---------------------------------------------------------------- models
@@ -132,19 +137,19 @@ template <typename T> struct CarModel { // systems.py:27-57
     static constexpr bool fx_nz(int i, int j) { return i == j || (i < 2 && j >= 2); }
     static constexpr bool fx_one(int i, int j) { return i == j; }
     static constexpr bool fu_nz(int i, int j) { return (i == 2 && j == 0) || (i == 3 && j == 1); }
-    template <class P>
-    static __device__ __forceinline__ void step(const P &p, int, const T (&x)[NX], const T (&u)[NU], T (&xn)[NX]) {
+    template <bool FAST, class P>
+    static __device__ __forceinline__ void step(const P &p, int, const T (&x)[NX], const T (&u)[NU], T (&xn)[NX], bool &bad) {
         T s, c;
-        sincos_(x[3], s, c);
+        sincos_<FAST>(x[3], s, c, bad);
         xn[0] = fma_(x[2] * c, p.dt, x[0]);
         xn[1] = fma_(x[2] * s, p.dt, x[1]);
         xn[2] = fma_(u[0], p.dt, x[2]);
         xn[3] = fma_(u[1], p.dt, x[3]);
     }
-    template <class P>
-    static __device__ __forceinline__ void jac(const P &p, int, const T (&x)[NX], const T (&)[NU], T (&fx)[NX][NX], T (&fu)[NX][NU]) {
+    template <bool FAST, class P>
+    static __device__ __forceinline__ void jac(const P &p, int, const T (&x)[NX], const T (&)[NU], T (&fx)[NX][NX], T (&fu)[NX][NU], bool &bad) {
         T s, c;
-        sincos_(x[3], s, c);
+        sincos_<FAST>(x[3], s, c, bad);
         fx[0][2] = c * p.dt;
         fx[0][3] = (-s * x[2]) * p.dt;
         fx[1][2] = s * p.dt;
@@ -160,20 +165,20 @@ template <typename T> struct CarAccModel { // systems.py:59-90
     static constexpr bool fx_nz(int i, int j) { return i == j || (i < 2 && (j == 2 || j == 4)) || (i == 2 && j == 3); }
     static constexpr bool fx_one(int i, int j) { return i == j; }
     static constexpr bool fu_nz(int i, int j) { return (i == 3 && j == 0) || (i == 4 && j == 1); }
-    template <class P>
-    static __device__ __forceinline__ void step(const P &p, int, const T (&x)[NX], const T (&u)[NU], T (&xn)[NX]) {
+    template <bool FAST, class P>
+    static __device__ __forceinline__ void step(const P &p, int, const T (&x)[NX], const T (&u)[NU], T (&xn)[NX], bool &bad) {
         T s, c;
-        sincos_(x[4], s, c);
+        sincos_<FAST>(x[4], s, c, bad);
         xn[0] = fma_(x[2] * c, p.dt, x[0]);
         xn[1] = fma_(x[2] * s, p.dt, x[1]);
         xn[2] = fma_(x[3], p.dt, x[2]);
         xn[3] = fma_(u[0], p.dt, x[3]);
         xn[4] = fma_(u[1], p.dt, x[4]);
     }
-    template <class P>
-    static __device__ __forceinline__ void jac(const P &p, int, const T (&x)[NX], const T (&)[NU], T (&fx)[NX][NX], T (&fu)[NX][NU]) {
+    template <bool FAST, class P>
+    static __device__ __forceinline__ void jac(const P &p, int, const T (&x)[NX], const T (&)[NU], T (&fx)[NX][NX], T (&fu)[NX][NU], bool &bad) {
         T s, c;
-        sincos_(x[4], s, c);
+        sincos_<FAST>(x[4], s, c, bad);
         fx[0][2] = c * p.dt;
         fx[0][4] = (-s * x[2]) * p.dt;
         fx[1][2] = s * p.dt;
@@ -190,18 +195,18 @@ template <typename T> struct DubinsModel { // systems.py:92-121
     static constexpr bool fx_nz(int i, int j) { return i == j || (i < 2 && j == 2); }
     static constexpr bool fx_one(int i, int j) { return i == j; }
     static constexpr bool fu_nz(int i, int j) { return j == 0 || (i == 2 && j == 1); }
-    template <class P>
-    static __device__ __forceinline__ void step(const P &p, int, const T (&x)[NX], const T (&u)[NU], T (&xn)[NX]) {
+    template <bool FAST, class P>
+    static __device__ __forceinline__ void step(const P &p, int, const T (&x)[NX], const T (&u)[NU], T (&xn)[NX], bool &bad) {
         T s, c;
-        sincos_(x[2], s, c);
+        sincos_<FAST>(x[2], s, c, bad);
         xn[0] = fma_(u[0] * c, p.dt, x[0]);
         xn[1] = fma_(u[0] * s, p.dt, x[1]);
         xn[2] = fma_(u[0] * u[1], p.dt, x[2]);
     }
-    template <class P>
-    static __device__ __forceinline__ void jac(const P &p, int, const T (&x)[NX], const T (&u)[NU], T (&fx)[NX][NX], T (&fu)[NX][NU]) {
+    template <bool FAST, class P>
+    static __device__ __forceinline__ void jac(const P &p, int, const T (&x)[NX], const T (&u)[NU], T (&fx)[NX][NX], T (&fu)[NX][NU], bool &bad) {
         T s, c;
-        sincos_(x[2], s, c);
+        sincos_<FAST>(x[2], s, c, bad);
         fx[0][2] = (-s * u[0]) * p.dt;
         fx[1][2] = (c * u[0]) * p.dt;
         fu[0][0] = c * p.dt;
@@ -329,8 +334,8 @@ __global__ __launch_bounds__(64) void cost_kernel(Params<T, M::NX, M::NU> p) {
 // positive the matrix is not positive definite: fall back to LU with partial
 // pivoting on the full matrix, which is what numpy.linalg.inv does
 // (ilqr.py:99), and flag the problem.
-template <typename T, int NU, int NR>
-__device__ __forceinline__ int solve_quu(const T (&A)[NU][NU], T (&Bm)[NU][NR]) {
+template <typename T, int NU, int NR, bool ASSUME_PD>
+__device__ __forceinline__ int solve_quu(const T (&A)[NU][NU], T (&Bm)[NU][NR], bool &bad) {
     // Bm holds the right-hand sides on entry (already negated) and the solution on exit
     T L[NU][NU], d[NU], dinv[NU];
     bool pd = true;
@@ -350,7 +355,10 @@ __device__ __forceinline__ int solve_quu(const T (&A)[NU][NU], T (&Bm)[NU][NR]) 
             L[i][j] = s * dinv[j];
         }
     }
-    if (__builtin_expect(pd, 1)) {
+    // ASSUME_PD: no branch here (the time step stays one basic block); a pivot that is not
+    // positive is reported through `bad` and the caller redoes its sweep with ASSUME_PD = false
+    if (ASSUME_PD) bad = bad || !pd;
+    if (ASSUME_PD || __builtin_expect(pd, 1)) {
 #pragma unroll
         for (int c = 0; c < NR; ++c) {
             T y[NU];
@@ -410,10 +418,10 @@ __device__ __forceinline__ int solve_quu(const T (&A)[NU][NU], T (&Bm)[NU][NR]) 
 // ---------------------------------------------------------------- backward
 // One Riccati step: consumes (x, u, xref) of step t and the value function of
 // step t+1, produces the gains of step t and the value function of step t.
-template <typename T, class M, bool DIAG, int CONSTR, class P>
+template <typename T, class M, bool DIAG, int CONSTR, bool FAST, class P>
 __device__ __forceinline__ int riccati_step(const P &p, int t, const T (&x)[M::NX], const T (&u)[M::NU], const T (&xr)[M::NX],
                                             T bcx, T bcy, T brad, T (&Vx)[M::NX], T (&Vxx)[M::NX][M::NX],
-                                            T (&Kt)[M::NU][M::NX], T (&kt)[M::NU]) {
+                                            T (&Kt)[M::NU][M::NX], T (&kt)[M::NU], bool &bad) {
     constexpr int NX = M::NX, NU = M::NU;
     T e[NX], lx[NX], lu[NU], lxx[NX][NX];
 #pragma unroll
@@ -453,7 +461,7 @@ __device__ __forceinline__ int riccati_step(const P &p, int t, const T (&x)[M::N
 #pragma unroll
         for (int j = 0; j < NU; ++j) fu[i][j] = T(0);
     }
-    M::jac(p, t, x, u, fx, fu);
+    M::template jac<FAST>(p, t, x, u, fx, fu, bad);
 
     // Qx = l_x + fx' Vx ; Qu = l_u + fu' Vx (ilqr.py:93-94)
     T Qx[NX], Qu[NU];
@@ -551,7 +559,7 @@ __device__ __forceinline__ int riccati_step(const P &p, int t, const T (&x)[M::N
 #pragma unroll
         for (int j = 0; j < NX; ++j) rhs[i][j + 1] = -Qux[i][j];
     }
-    int st = solve_quu<T, NU, NX + 1>(Quu, rhs);
+    int st = solve_quu<T, NU, NX + 1, FAST>(Quu, rhs, bad);
     if (CONSTR & 1) {
         // cilqr.py:112-134.  min 1/2 du'Quu du + (2 Qu)'du, lo-u <= du <= hi-u.  The result is
         // used only when every multiplier exceeds lambda in magnitude, i.e. the minimiser is a
@@ -563,7 +571,7 @@ __device__ __forceinline__ int riccati_step(const P &p, int t, const T (&x)[M::N
         for (int mask = 0; mask < (1 << NU); ++mask) {
             T c[NU];
 #pragma unroll
-            for (int j = 0; j < NU; ++j) c[j] = ((mask >> j) & 1) ? (p.hi[j] - u[j]) : (p.lo[j] - u[j]);
+            for (int j = 0; j < NU; ++j) c[j] = ((mask >> j) & 1) ? (p.qhi[j] - u[j]) : (p.qlo[j] - u[j]);
             bool ok = true;
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
@@ -616,25 +624,13 @@ template <typename T, int NX, int NU> struct StepRow { // the rows of one time s
     T x[NX], u[NU], xr[NX], cx, cy, rad;
 };
 
-template <typename T, class M, bool DIAG, int CONSTR, int PF>
-__global__ __launch_bounds__(64) void backward_kernel(Params<T, M::NX, M::NU> p) {
+// One reverse sweep over the horizon for the problem of this lane; returns status bits and
+// sets `bad` if the fast trigonometry met an argument outside its range.
+template <typename T, class M, bool DIAG, int CONSTR, int PF, bool FAST, class P>
+__device__ __forceinline__ int backward_sweep(const P &p, const T *Xt, const T *Rt, const T *Ut, const T *Cp, const T *Dp,
+                                              T *Kp, T *kp, bool &bad) {
     constexpr int NX = M::NX, NU = M::NU;
-    const int b0 = blockIdx.x * 64 + threadIdx.x;
-    const bool valid = b0 < p.B;
-    const int b = valid ? b0 : p.B - 1;
-    const bool active = valid && p.converged[b] == 0;
-    if (__ballot(active) == 0ull) return;
     const int T1 = p.N - 1;
-    constexpr bool BARRIER_ = (CONSTR & 2) != 0;
-    const int tile = b >> 6, ln = b & 63;
-    const T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
-    const T *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
-    const T *Ut = tile_ptr(p.U, tile, (p.N - 1) * NU, ln);
-    const T *Cp = BARRIER_ ? tile_ptr(p.centers, tile, p.N * 2, ln) : nullptr;
-    const T *Dp = BARRIER_ ? tile_ptr(p.radius, tile, p.N, ln) : nullptr;
-    T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
-    T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
-
     auto load_row = [&](int t, StepRow<T, NX, NU> &r) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -675,8 +671,7 @@ __global__ __launch_bounds__(64) void backward_kernel(Params<T, M::NX, M::NU> p)
             for (int j = 0; j < NX; ++j) Vxx[i][j] = (DIAG && i != j) ? T(0) : p.Qf2[i * NX + j];
         }
         if (CONSTR & 2)
-            barrier_terms<T, NX, true>(p, x, Cp[(T1 * 2 + 0) * TILE], Cp[(T1 * 2 + 1) * TILE],
-                                       Dp[T1 * TILE], Vx, Vxx);
+            barrier_terms<T, NX, true>(p, x, Cp[(T1 * 2 + 0) * TILE], Cp[(T1 * 2 + 1) * TILE], Dp[T1 * TILE], Vx, Vxx);
     }
 
     StepRow<T, NX, NU> ring[PF];
@@ -692,17 +687,47 @@ __global__ __launch_bounds__(64) void backward_kernel(Params<T, M::NX, M::NU> p)
             StepRow<T, NX, NU> cur = ring[s];
             if (t - PF >= 0) load_row(t - PF, ring[s]);
             T Kt[NU][NX], kt[NU];
-            status |= riccati_step<T, M, DIAG, CONSTR>(p, t, cur.x, cur.u, cur.xr, cur.cx, cur.cy, cur.rad, Vx, Vxx, Kt, kt);
-            if (active) {
+            status |= riccati_step<T, M, DIAG, CONSTR, FAST>(p, t, cur.x, cur.u, cur.xr, cur.cx, cur.cy, cur.rad, Vx, Vxx, Kt, kt, bad);
+            // every lane stores, also those of converged problems (their trajectory has not
+            // changed, so they rewrite the same bits) and the padding lanes of the last tile: a
+            // branch around the stores would make the number of outstanding memory operations
+            // path-dependent and force full drains of the memory queue in the loop
 #pragma unroll
-                for (int i = 0; i < NU; ++i) {
-                    kp[(t * NU + i) * TILE] = kt[i];
+            for (int i = 0; i < NU; ++i) {
+                kp[(t * NU + i) * TILE] = kt[i];
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) Kp[((t * NU + i) * NX + j) * TILE] = Kt[i][j];
-                }
+                for (int j = 0; j < NX; ++j) Kp[((t * NU + i) * NX + j) * TILE] = Kt[i][j];
             }
         }
     }
+    return status;
+}
+
+template <typename T, class M, bool DIAG, int CONSTR, int PF>
+__global__ __launch_bounds__(64) void backward_kernel(Params<T, M::NX, M::NU> p) {
+    constexpr int NX = M::NX, NU = M::NU;
+    const int b0 = blockIdx.x * 64 + threadIdx.x;
+    const bool valid = b0 < p.B;
+    const int b = valid ? b0 : p.B - 1;
+    const bool active = valid && p.converged[b] == 0;
+    if (__ballot(active) == 0ull) return;
+    const int T1 = p.N - 1;
+    constexpr bool BARRIER_ = (CONSTR & 2) != 0;
+    const int tile = b0 >> 6, ln = b0 & 63; // buffers are padded to whole tiles
+    const T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
+    const T *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
+    const T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
+    const T *Cp = BARRIER_ ? tile_ptr(p.centers, tile, p.N * 2, ln) : nullptr;
+    const T *Dp = BARRIER_ ? tile_ptr(p.radius, tile, p.N, ln) : nullptr;
+    T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
+    T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    bool bad = false;
+    int status = backward_sweep<T, M, DIAG, CONSTR, PF, true>(p, Xt, Rt, Ut, Cp, Dp, Kp, kp, bad);
+    // rare: an angle outside the fast trigonometric range or a Quu that is not positive definite
+    // somewhere in the wave; redo with the library sine/cosine and the pivoted-LU fallback (lanes
+    // that did not need either get the same bits as before)
+    if (__ballot(bad && active) != 0ull)
+        status = backward_sweep<T, M, DIAG, CONSTR, 1, false>(p, Xt, Rt, Ut, Cp, Dp, Kp, kp, bad);
     if (active && status != 0 && p.status) p.status[b] |= status;
 }
 
@@ -721,10 +746,11 @@ __device__ __forceinline__ void control_update(const P &p, T alpha, const T (&x)
 #pragma unroll
         for (int j = 1; j < NX; ++j) fb = fma_(Kt[i][j], dx[j], fb);
         T v = fma_(alpha, kt[i], up[i]) + fb;
-        if (p.control_limited) {
-            v = (p.lo[i] > v) ? p.lo[i] : v; // max(v, lo) with Python's NaN behaviour
-            v = (p.hi[i] < v) ? p.hi[i] : v; // min(v, hi)
-        }
+        // min(max(v, lo), hi) with Python's NaN behaviour (a NaN stays a NaN).  Without control
+        // limits the host passes lo = -inf, hi = +inf, which makes this the identity, so the time
+        // step has no branch.
+        v = (p.lo[i] > v) ? p.lo[i] : v;
+        v = (p.hi[i] < v) ? p.hi[i] : v;
         un[i] = v;
     }
 }
@@ -738,30 +764,12 @@ template <typename T, int NX, int NU> struct FwdRow { // rows of one step shared
 // rounds continue (in increasing index order, so the largest improving step
 // wins exactly as in the serial search) until every problem of the wave has a
 // winner or the candidates are exhausted.
-template <typename T, class M, bool DIAG, bool BARRIER, int L, int A>
-__global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T, M::NX, M::NU> p) {
+template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool FAST, class P>
+__device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T *Rt, const T *Ut, const T *Kp, const T *kp,
+                                                const T *Cp, const T *Dp, int al, bool active, T Jcur, int &best, T &best_cost,
+                                                bool &bad) {
     constexpr int NX = M::NX, NU = M::NU;
-    constexpr int PPW = 64 / L; // problems per wave
-    const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int pl = lane / L, al = lane % L;
-    const int b0 = wave * PPW + pl;
-    const bool valid = b0 < p.B;
-    const int b = valid ? b0 : p.B - 1;
-    const bool active = valid && p.converged[b] == 0;
-    if (__ballot(active) == 0ull) return;
     const int T1 = p.N - 1;
-    const T Jcur = p.J[b];
-    constexpr bool BARRIER_ = BARRIER;
-    const int tile = b >> 6, ln = b & 63;
-    const T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
-    const T *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
-    const T *Ut = tile_ptr(p.U, tile, (p.N - 1) * NU, ln);
-    const T *Cp = BARRIER_ ? tile_ptr(p.centers, tile, p.N * 2, ln) : nullptr;
-    const T *Dp = BARRIER_ ? tile_ptr(p.radius, tile, p.N, ln) : nullptr;
-    const T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
-    const T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
-
     auto load_row = [&](int t, FwdRow<T, NX, NU> &r) {
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
@@ -783,9 +791,8 @@ __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T,
             r.cx = r.cy = r.rad = T(0);
         }
     };
-
-    int best = 0x7fffffff;
-    T best_cost = T(0);
+    best = 0x7fffffff;
+    best_cost = T(0);
     T dlx[NX], dlxx[NX][NX];
     for (int base = 0; base < p.n_alphas; base += L * A) {
         T x[A][NX], cost[A], alpha[A];
@@ -810,7 +817,7 @@ __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T,
                 T stage = quad_<T, NX, DIAG>(p.Q, e) + quad_<T, NU, DIAG>(p.R, un);
                 if (BARRIER && t > 0) stage += barrier_terms<T, NX, false>(p, x[j], r.cx, r.cy, r.rad, dlx, dlxx);
                 cost[j] += stage;
-                M::step(p, t, x[j], un, xn);
+                M::template step<FAST>(p, t, x[j], un, xn, bad);
 #pragma unroll
                 for (int i = 0; i < NX; ++i) x[j][i] = xn[i];
             }
@@ -856,9 +863,42 @@ __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T,
         }
         if (__ballot(active && best == 0x7fffffff) == 0ull) break;
     }
+}
+
+template <typename T, class M, bool DIAG, bool BARRIER, int L, int A>
+__global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T, M::NX, M::NU> p) {
+    constexpr int NX = M::NX, NU = M::NU;
+    constexpr int PPW = 64 / L; // problems per wave
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int pl = lane / L, al = lane % L;
+    const int b0 = wave * PPW + pl;
+    const bool valid = b0 < p.B;
+    const int b = valid ? b0 : p.B - 1;
+    const bool active = valid && p.converged[b] == 0;
+    if (__ballot(active) == 0ull) return;
+    const int T1 = p.N - 1;
+    const T Jcur = p.J[b];
+    const int tile = b >> 6, ln = b & 63;
+    const T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
+    const T *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
+    const T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
+    const T *Cp = BARRIER ? tile_ptr(p.centers, tile, p.N * 2, ln) : nullptr;
+    const T *Dp = BARRIER ? tile_ptr(p.radius, tile, p.N, ln) : nullptr;
+    const T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
+    const T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    int best;
+    T best_cost;
+    bool bad = false;
+    evaluate_rounds<T, M, DIAG, BARRIER, L, A, true>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, best, best_cost, bad);
+    // an angle outside the fast trigonometric range anywhere in the wave: redo with the library
+    // routine and tell the commit kernel to do the same for these problems
+    const bool wave_bad = __ballot(bad && active) != 0ull;
+    if (wave_bad) evaluate_rounds<T, M, DIAG, BARRIER, L, A, false>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, best, best_cost, bad);
     if (active && al == 0) {
         p.alpha_idx[b] = (best == 0x7fffffff) ? -1 : best;
         p.Jtry[b] = best_cost;
+        p.slow_trig[b] = wave_bad ? 1 : 0;
     }
 }
 
@@ -867,40 +907,10 @@ __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T,
 // overwrites X and U in place (each lane reads a row before it overwrites it);
 // problems without an accepted step keep their trajectory and become converged
 // (ilqr.py:69-73).
-template <typename T, class M, int PF>
-__global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, int it) {
+template <typename T, class M, int PF, bool FAST, class P>
+__device__ __forceinline__ void commit_sweep(const P &p, T *Xt, T *Ut, const T *Kp, const T *kp, T alpha, bool roll) {
     constexpr int NX = M::NX, NU = M::NU;
-    const int b0 = blockIdx.x * 64 + threadIdx.x;
-    const bool valid = b0 < p.B;
-    const int b = valid ? b0 : p.B - 1;
-    const bool active = valid && p.converged[b] == 0;
-    if (__ballot(active) == 0ull) return;
-    const size_t B = p.B;
     const int T1 = p.N - 1;
-    const int tile = b >> 6, ln = b & 63;
-    T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
-    T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
-    const T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
-    const T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
-    const int idx = p.alpha_idx[b];
-    const bool roll = active && idx >= 0;
-    if (active) {
-        p.iters[b] += 1;
-        T Jn = roll ? p.Jtry[b] : p.J[b];
-        if (roll) {
-            p.J[b] = Jn;
-            if (p.status && !(fabs_(Jn) < inf_<T>())) p.status[b] |= ILQR_STATUS_NONFINITE_;
-        } else {
-            p.converged[b] = 1;
-        }
-        if (it < p.hist_cap) {
-            if (p.hist_cost) p.hist_cost[size_t(it) * B + b] = Jn;
-            if (p.hist_alpha) p.hist_alpha[size_t(it) * B + b] = idx;
-        }
-    }
-    if (__ballot(roll) == 0ull) return;
-    const T alpha = pow2_neg<T>(roll ? idx : 0);
-
     struct Row {
         T K[NU][NX], k[NU], xp[NX], up[NU];
     };
@@ -918,32 +928,69 @@ __global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, i
     T x[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = Xt[i * TILE];
-    Row ring[PF];
+    Row nxt;
+    load_row(0, nxt);
+    T xlast[NX]; // previous states of the terminal step, needed to keep lanes without a winner unchanged
 #pragma unroll
-    for (int s = 0; s < PF; ++s)
-        if (s < T1) load_row(s, ring[s]);
-    for (int tb = 0; tb < T1; tb += PF) {
+    for (int i = 0; i < NX; ++i) xlast[i] = Xt[(T1 * NX + i) * TILE];
+    bool bad = false;
+    for (int t = 0; t < T1; ++t) {
+        Row r = nxt;
+        // the row of step t+1 is read here, before the store to it below
+        if (t + 1 < T1) load_row(t + 1, nxt);
+        T un[NU], xn[NX];
+        control_update<T, M>(p, alpha, x, r.xp, r.up, r.K, r.k, un);
+        M::template step<FAST>(p, t, x, un, xn, bad);
 #pragma unroll
-        for (int s = 0; s < PF; ++s) {
-            const int t = tb + s;
-            if (t >= T1) break;
-            Row r = ring[s];
-            // the row of step t+PF is read here, before any store to it below (stores reach
-            // at most row t+1 <= t+PF)
-            if (t + PF < T1) load_row(t + PF, ring[s]);
-            T un[NU], xn[NX];
-            control_update<T, M>(p, alpha, x, r.xp, r.up, r.K, r.k, un);
-            M::step(p, t, x, un, xn);
+        for (int i = 0; i < NX; ++i) x[i] = xn[i];
+        // Every lane stores; a lane whose problem has no accepted step writes back the values it
+        // read (no branch around the stores: see backward_sweep)
 #pragma unroll
-            for (int i = 0; i < NX; ++i) x[i] = xn[i];
-            if (roll) {
+        for (int i = 0; i < NU; ++i) Ut[(t * NU + i) * TILE] = roll ? un[i] : r.up[i];
 #pragma unroll
-                for (int i = 0; i < NU; ++i) Ut[(t * NU + i) * TILE] = un[i];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) Xt[((t + 1) * NX + i) * TILE] = xn[i];
-            }
+        for (int i = 0; i < NX; ++i) Xt[((t + 1) * NX + i) * TILE] = roll ? xn[i] : (t + 1 < T1 ? nxt.xp[i] : xlast[i]);
+    }
+}
+
+template <typename T, class M, int PF>
+__global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, int it) {
+    constexpr int NX = M::NX, NU = M::NU;
+    const int b0 = blockIdx.x * 64 + threadIdx.x;
+    const bool valid = b0 < p.B;
+    const int b = valid ? b0 : p.B - 1;
+    const bool active = valid && p.converged[b] == 0;
+    if (__ballot(active) == 0ull) return;
+    const int T1 = p.N - 1;
+    const int tile = b0 >> 6, ln = b0 & 63; // buffers are padded to whole tiles
+    T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
+    T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
+    const T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
+    const T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    const int idx = p.alpha_idx[b];
+    const bool roll = active && idx >= 0;
+    const bool slow = roll && p.slow_trig[b] != 0;
+    if (active) {
+        p.iters[b] += 1;
+        T Jn = roll ? p.Jtry[b] : p.J[b];
+        if (roll) {
+            p.J[b] = Jn;
+            if (p.status && !(fabs_(Jn) < inf_<T>())) p.status[b] |= ILQR_STATUS_NONFINITE_;
+        } else {
+            p.converged[b] = 1;
+        }
+        if (it < p.hist_cap) {
+            if (p.hist_cost) p.hist_cost[size_t(it) * p.hist_stride + b] = Jn;
+            if (p.hist_alpha) p.hist_alpha[size_t(it) * p.hist_stride + b] = idx;
         }
     }
+    if (__ballot(roll) == 0ull) return;
+    const T alpha = pow2_neg<T>(roll ? idx : 0);
+    // the trajectory is overwritten in place, so the choice between the fast trigonometry and
+    // the library routine is made up front, from what the evaluate kernel saw on these problems
+    if (__ballot(slow) == 0ull)
+        commit_sweep<T, M, PF, true>(p, Xt, Ut, Kp, kp, alpha, roll);
+    else
+        commit_sweep<T, M, 1, false>(p, Xt, Ut, Kp, kp, alpha, roll);
 }
 
 // ---------------------------------------------------------------- layout conversion

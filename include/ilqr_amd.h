@@ -82,7 +82,8 @@ typedef struct ilqr_desc {
     int32_t n_alphas;        /* line-search candidates 2^0..2^-(n_alphas-1); 0 = derive from alpha_floor */
     int32_t lanes_per_problem; /* forward mapping: lanes of a wave that share one problem (1,2,4,8,16); 0 = auto */
     int32_t alphas_per_lane;   /* step sizes each lane rolls out per round (1,2,4,8,16); 0 = auto */
-    int32_t reserved0;
+    int32_t n_streams;         /* ilqr_solve splits the batch into this many tile ranges, each on a stream of
+                                  its own, so phases of different parts overlap (1..8); 0 = auto */
     double dt;               /* system.dt (systems.py:30); the solver's own dt argument is unused (ilqr.py:20) */
     double lm_parameter;     /* ilqr.py:30, added to Vxx (ilqr.py:95) */
     double alpha_floor;      /* 1e-4 (ilqr.py:71) or alpha_terminal (cilqr.py:41) */
