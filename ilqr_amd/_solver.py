@@ -47,7 +47,7 @@ class DeviceProblem:
             raise _lib.IlqrError("no GPU visible: the batched iLQR solve runs on the HIP device only")
         if getattr(system, "device_model_id", None) is None:
             raise _lib.IlqrError(
-                f"{type(system).__name__} has no device dynamics; use Car, CarAcceleration or DubinsCar")
+                f"{type(system).__name__} has no device dynamics; use Car, CarAcceleration, DubinsCar or LTVSystem")
         self.lib = _lib.lib()
         self.device = torch.device(device if device is not None else "cuda")
         self.np_dtype = _np_dtype(dtype)
@@ -111,6 +111,14 @@ class DeviceProblem:
             if constraint_mode & _lib.CONSTR_BARRIER:
                 self.centers = torch.zeros(Bp * N * 2, dtype=td, device=dev)
                 self.radius = torch.ones(Bp * N, dtype=td, device=dev)
+            self.ltv_A = self.ltv_B = None
+            if d.model == 3:  # table-driven LTV: the tables are shared by the whole batch
+                A = np.ascontiguousarray(system.A, dtype=self.np_dtype)
+                Bm = np.ascontiguousarray(system.B, dtype=self.np_dtype)
+                if A.shape != (N - 1, n, n) or Bm.shape != (N - 1, n, m):
+                    raise ValueError("LTVSystem tables must be A (N-1, n, n) and B (N-1, n, m)")
+                self.ltv_A = torch.from_numpy(A).to(dev)
+                self.ltv_B = torch.from_numpy(Bm).to(dev)
             self.hist_cost = self.hist_alpha = None
             if history:
                 self.hist_cost = torch.full((self.max_iter, B), float("nan"), dtype=td, device=dev)
@@ -127,6 +135,8 @@ class DeviceProblem:
         b.work = self.work.data_ptr()
         if self.centers is not None:
             b.centers, b.radius = self.centers.data_ptr(), self.radius.data_ptr()
+        if self.ltv_A is not None:
+            b.ltv_A, b.ltv_B = self.ltv_A.data_ptr(), self.ltv_B.data_ptr()
         if self.hist_cost is not None:
             b.hist_cost, b.hist_alpha = self.hist_cost.data_ptr(), self.hist_alpha.data_ptr()
             b.hist_capacity = self.max_iter
@@ -290,7 +300,8 @@ class BatchedSolverBase:
         lim = (tuple(s.control_lower_limit), tuple(s.control_upper_limit)) if s.control_limited else None
         return (self._B, self.horizon, int(self.maxIter), float(self.LM_parameter), float(s.dt),
                 np.asarray(self.Q).tobytes(), np.asarray(self.R).tobytes(), np.asarray(self.Qf).tobytes(),
-                bool(s.control_limited), lim, self._alpha_floor(), repr(sorted(self._extra_desc().items())))
+                bool(s.control_limited), lim, self._alpha_floor(), repr(sorted(self._extra_desc().items())),
+                id(getattr(s, "A", None)), id(getattr(s, "B", None)))
 
     def _ensure_device(self):
         key = self._key()

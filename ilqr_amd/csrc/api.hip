@@ -80,6 +80,11 @@ int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
     case ILQR_MODEL_CAR: want_n = 4; want_m = 2; ops = ops_car(d.dtype, diag); break;
     case ILQR_MODEL_CARACC: want_n = 5; want_m = 2; ops = ops_caracc(d.dtype, diag); break;
     case ILQR_MODEL_DUBINS: want_n = 3; want_m = 2; ops = ops_dubins(d.dtype, diag); break;
+    case ILQR_MODEL_LTV:
+        // table-driven x+ = A_t x + B_t u; built for n = 12, m = 4 with diagonal cost weights
+        if (d.n != 12 || d.m != 4) return ILQR_ERR_UNSUPPORTED;
+        want_n = 12; want_m = 4; ops = d.dtype == ILQR_F64 ? ops_ltv12x4_f64(diag) : ops_ltv12x4_f32(diag);
+        break;
     default: return ILQR_ERR_UNSUPPORTED;
     }
     if (d.n != want_n || d.m != want_m) return ILQR_ERR_INVALID;
@@ -100,7 +105,7 @@ int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
         // pure speed choice.  Few lanes per problem means more independent rollouts per lane
         // (instruction-level parallelism, shared row loads); many lanes per problem means more
         // waves, which small batches need to occupy the 1024 SIMDs.  Aim at >= 2048 waves.
-        L = 2;
+        L = d.n > 8 ? 8 : 2;
         while (L < 16 && (long)d.B * L < 131072L) L *= 2;
         A = 16 / L;
     } else if (L == 0 || A == 0) {
@@ -169,6 +174,7 @@ int ilqr_bind(ilqr_handle *h, const ilqr_buffers *b) {
     if (!b->X || !b->U || !b->Xref || !b->K || !b->k || !b->J || !b->converged || !b->iters || !b->alpha_idx || !b->work)
         return ILQR_ERR_NOT_BOUND;
     if ((h->ctx.d.constraint_mode & ILQR_CONSTR_BARRIER) && (!b->centers || !b->radius)) return ILQR_ERR_NOT_BOUND;
+    if (h->ctx.d.model == ILQR_MODEL_LTV && (!b->ltv_A || !b->ltv_B)) return ILQR_ERR_NOT_BOUND;
     if ((b->hist_cost || b->hist_alpha) && b->hist_capacity <= 0) return ILQR_ERR_INVALID;
     h->ctx.b = *b;
     h->ctx.bound = true;
@@ -251,10 +257,17 @@ int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream) {
         rc = hip_rc(h->ops->cost(part[s], 0, h->part_stream[s]));
         if (rc != ILQR_OK) return rc;
     }
+    // The line search is arithmetic-bound, the backward pass and the commit are bandwidth-bound.
+    // A token (an event chain) lets only one part run its line search at a time, which pushes the
+    // parts into opposite phases: while one computes, the others stream.
+    int prev = -1;
     for (int it = 0; it < max_iter && rc == ILQR_OK; ++it)
         for (int s = 0; s < h->n_parts && rc == ILQR_OK; ++s) {
             rc = hip_rc(h->ops->backward(part[s], 0, h->part_stream[s]));
+            if (rc == ILQR_OK && prev >= 0) rc = hip_rc(hipStreamWaitEvent(h->part_stream[s], h->join_event[prev], 0));
             if (rc == ILQR_OK) rc = hip_rc(h->ops->evaluate(part[s], 0, h->part_stream[s]));
+            if (rc == ILQR_OK) rc = hip_rc(hipEventRecord(h->join_event[s], h->part_stream[s]));
+            prev = s;
             if (rc == ILQR_OK) rc = hip_rc(h->ops->commit(part[s], it, h->part_stream[s]));
         }
     for (int s = 0; s < h->n_parts; ++s) {

@@ -29,6 +29,9 @@ struct ModelOps {
 const ModelOps *ops_car(int dtype, bool diag);
 const ModelOps *ops_caracc(int dtype, bool diag);
 const ModelOps *ops_dubins(int dtype, bool diag);
+// diagonal cost weights only (keeps the build of the large model small); nullptr otherwise
+const ModelOps *ops_ltv12x4_f64(bool diag);
+const ModelOps *ops_ltv12x4_f32(bool diag);
 
 template <typename T, int NX, int NU> static Params<T, NX, NU> make_params(const HostCtx &c) {
     Params<T, NX, NU> p;
@@ -149,17 +152,27 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
     }
     template <bool BARRIER> static hipError_t eval_b(const HostCtx &c, hipStream_t s) {
         const int key = c.L * 100 + c.A;
-        switch (key) {
-        case 1601: return eval_la<BARRIER, 16, 1>(c, s);
-        case 802: return eval_la<BARRIER, 8, 2>(c, s);
-        case 404: return eval_la<BARRIER, 4, 4>(c, s);
-        case 116: return eval_la<BARRIER, 1, 16>(c, s);
-        case 208: return eval_la<BARRIER, 2, 8>(c, s);
-        case 801: return eval_la<BARRIER, 8, 1>(c, s);
-        case 401: return eval_la<BARRIER, 4, 1>(c, s);
-        case 104: return eval_la<BARRIER, 1, 4>(c, s);
-        case 204: return eval_la<BARRIER, 2, 4>(c, s);
-        default: return hipErrorInvalidValue;
+        if constexpr (M::NX > 8) {
+            // large models: only the mappings with few step sizes per lane are built (more would
+            // not fit the register file)
+            switch (key) {
+            case 1601: return eval_la<BARRIER, 16, 1>(c, s);
+            case 802: return eval_la<BARRIER, 8, 2>(c, s);
+            default: return hipErrorInvalidValue;
+            }
+        } else {
+            switch (key) {
+            case 1601: return eval_la<BARRIER, 16, 1>(c, s);
+            case 802: return eval_la<BARRIER, 8, 2>(c, s);
+            case 404: return eval_la<BARRIER, 4, 4>(c, s);
+            case 116: return eval_la<BARRIER, 1, 16>(c, s);
+            case 208: return eval_la<BARRIER, 2, 8>(c, s);
+            case 801: return eval_la<BARRIER, 8, 1>(c, s);
+            case 401: return eval_la<BARRIER, 4, 1>(c, s);
+            case 104: return eval_la<BARRIER, 1, 4>(c, s);
+            case 204: return eval_la<BARRIER, 2, 4>(c, s);
+            default: return hipErrorInvalidValue;
+            }
         }
     }
     static hipError_t evaluate(const HostCtx &c, int, hipStream_t s) {
@@ -185,5 +198,4 @@ template <template <typename> class MT> static const ModelOps *ops_for(int dtype
     if (dtype == ILQR_F32) return diag ? Launch<float, MT, true>::table() : Launch<float, MT, false>::table();
     return nullptr;
 }
-
 } // namespace ilqr

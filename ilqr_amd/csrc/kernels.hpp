@@ -216,6 +216,45 @@ template <typename T> struct DubinsModel { // systems.py:92-121
     }
 };
 
+// Table-driven linear time-varying model x+ = A_t x + B_t u (no reference counterpart: the
+// reference's model_f(x, u) has no time argument).  A_t [T][NX][NX] and B_t [T][NX][NU] are
+// shared by the whole batch, so every lane of a wave reads the same address: the loads are
+// scalar and the matrix entries arrive as SGPR operands.
+template <typename T, int NX_, int NU_> struct LtvModelT {
+    static constexpr int NX = NX_, NU = NU_;
+    static constexpr bool HAS_BARRIER = false;
+    static constexpr bool fx_nz(int, int) { return true; }
+    static constexpr bool fx_one(int, int) { return false; }
+    static constexpr bool fu_nz(int, int) { return true; }
+    template <bool FAST, class P>
+    static __device__ __forceinline__ void step(const P &p, int t, const T (&x)[NX], const T (&u)[NU], T (&xn)[NX], bool &) {
+        const T *A = p.ltvA + (size_t)t * NX * NX;
+        const T *Bm = p.ltvB + (size_t)t * NX * NU;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            T s = A[i * NX] * x[0];
+#pragma unroll
+            for (int j = 1; j < NX; ++j) s = fma_(A[i * NX + j], x[j], s);
+#pragma unroll
+            for (int j = 0; j < NU; ++j) s = fma_(Bm[i * NU + j], u[j], s);
+            xn[i] = s;
+        }
+    }
+    template <bool FAST, class P>
+    static __device__ __forceinline__ void jac(const P &p, int t, const T (&)[NX], const T (&)[NU], T (&fx)[NX][NX], T (&fu)[NX][NU], bool &) {
+        const T *A = p.ltvA + (size_t)t * NX * NX;
+        const T *Bm = p.ltvB + (size_t)t * NX * NU;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) fx[i][j] = A[i * NX + j];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) fu[i][j] = Bm[i * NU + j];
+        }
+    }
+};
+template <typename T> using Ltv12x4Model = LtvModelT<T, 12, 4>;
+
 // ---------------------------------------------------------------- cost pieces
 // e' W e with W dense row-major, as (e' W) e (ilqr.py:42), or diagonal.
 template <typename T, int D, bool DIAG>

@@ -237,3 +237,40 @@ def bubbles_for(target_states, radius=4.0, vel_bounds=(-1.0, 14.0)):
     centers = np.ascontiguousarray(target_states[..., :2])
     rad = np.full(target_states.shape[:-1], float(radius))
     return centers, rad, np.asarray(vel_bounds, dtype=float)
+
+
+def ltv_system(N=500, n=12, m=4, seed=2024, dt=0.05):
+    """Synthetic quadrotor-sized linear time-varying system: A_t = I + dt*M_t with a slowly
+    rotating, mildly damped M_t, and B_t = dt*G_t.  Returns (A (N-1,n,n), B (N-1,n,m), Q, R).
+    No reference counterpart (the reference's model_f has no time argument)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    M0 = rng.normal(size=(n, n)) * 0.4
+    M0 = 0.5 * (M0 - M0.T) - 0.15 * np.eye(n)          # skew part + damping: stable
+    M1 = rng.normal(size=(n, n)) * 0.1
+    G0 = rng.normal(size=(n, m))
+    G1 = rng.normal(size=(n, m)) * 0.3
+    A = np.empty((N - 1, n, n))
+    Bm = np.empty((N - 1, n, m))
+    for t in range(N - 1):
+        ph = 2 * np.pi * t / (N - 1)
+        A[t] = np.eye(n) + dt * (M0 + np.sin(ph) * M1)
+        Bm[t] = dt * (G0 + np.cos(ph) * G1)
+    Q = np.diag(rng.uniform(1.0, 20.0, size=n))
+    R = np.diag(rng.uniform(0.5, 5.0, size=m))
+    return A, Bm, Q, R
+
+
+def ltv_batch(B, N=500, n=12, m=4, seed0=777, first=0):
+    """Per-problem smooth random targets, initial states and (zero) initial inputs for the LTV
+    system; problem b depends only on seed0 + b."""
+    tg = np.empty((B, N, n))
+    x0 = np.empty((B, n))
+    tt = np.linspace(0.0, 1.0, N)[:, None]
+    for j in range(B):
+        rng = np.random.Generator(np.random.PCG64(seed0 + first + j))
+        amp = rng.uniform(-2.0, 2.0, size=(3, n))
+        tg[j] = amp[0] * np.sin(2 * np.pi * tt) + amp[1] * np.cos(np.pi * tt) + amp[2] * tt
+        x0[j] = rng.uniform(-1.0, 1.0, size=n)
+    st = np.zeros((B, N, n))
+    st[:, 0] = x0
+    return {"target_states": tg, "init_inputs": np.zeros((B, N - 1, m)), "x0": x0, "init_states": st}

@@ -445,3 +445,64 @@ def test_full_size_batch_properties(ilqr_cls, oracle):
     st0, it0, cv0 = opt.states.copy(), opt.iterations.copy(), opt.converge.copy()
     opt()
     assert np.array_equal(opt.states[cv0], st0[cv0])
+
+
+# --------------------------------------------------------------------------- LTV n=12, m=4
+def ltv_setup(N, limits=True):
+    from ilqr_amd import problems, systems
+    A, Bm, Q, R = problems.ltv_system(N=N)
+    s = systems.LTVSystem(A, Bm, dt=0.05)
+    s.set_cost(Q, R)
+    if limits:
+        s.set_control_limit([-3.0] * 4, [3.0] * 4)
+    return s
+
+
+@pytest.mark.parametrize("limits", [True, False])
+def test_ltv12x4_matches_oracle(ilqr_cls, oracle, limits):
+    """Table-driven LTV system (n=12, m=4): an extension without a reference counterpart
+    (parity UNPINNED); the checker is the oracle's generic dense statement of ilqr.py."""
+    from ilqr_amd import problems
+    N, B = 120, 70
+    s = ltv_setup(N, limits)
+    p = problems.ltv_batch(B, N)
+    opt = ilqr_cls(s, p["target_states"], s.dt, history=True)
+    opt.inputs, opt.states = p["init_inputs"].copy(), p["init_states"].copy()
+    dev = opt.upload()
+    dev.initial_cost()
+    dev.backward()
+    d = oracle.make_desc(s, N)
+    for b in (0, 33, 69):
+        Ko, ko, rc = oracle.backward(d, np.ascontiguousarray(p["target_states"][b]), p["init_states"][b].copy(),
+                                     p["init_inputs"][b].copy())
+        assert rc == 0
+        assert nrm(dev.download_K()[b], Ko) <= 1e-11 and nrm(dev.download_k()[b][:, :, 0], ko) <= 1e-11
+    opt()
+    r = oracle.solve_batch(d, p["target_states"], p["init_states"].copy(), p["init_inputs"].copy())
+    assert np.all(opt.status == 0)
+    for b in range(B):
+        # a linear-quadratic problem is solved by the first full step; everything after it is
+        # round-off (the iteration count there is not reproducible), so the GPU must only
+        # cover every iteration in which the oracle still made a real decrease
+        ro = int(r["iters"][b])
+        solid_o = noise_floor_mask(r["hist_cost"][b, :ro], r["cost0"][b])
+        last_solid = int(np.nonzero(solid_o)[0].max()) + 1 if solid_o.any() else 0
+        n = min(int(opt.iterations[b]), ro)
+        assert n >= last_solid and n >= 1
+        rel = np.abs(opt.cost_history[b, :n] - r["hist_cost"][b, :n]) / np.abs(r["hist_cost"][b, :n])
+        assert rel.max() <= 1e-9
+        assert np.array_equal(opt.alpha_history[b, :n][solid_o[:n]], r["hist_alpha"][b, :n][solid_o[:n]])
+
+
+def test_ltv12x4_fp32_mode(ilqr_cls, oracle):
+    from ilqr_amd import problems
+    N, B = 120, 8
+    s = ltv_setup(N)
+    p = problems.ltv_batch(B, N)
+    opt = ilqr_cls(s, p["target_states"], s.dt, history=True, dtype=np.float32)
+    opt.inputs, opt.states = p["init_inputs"].copy(), p["init_states"].copy()
+    opt()
+    d = oracle.make_desc(s, N)
+    r = oracle.solve_batch(d, p["target_states"], p["init_states"].copy(), p["init_inputs"].copy())
+    assert np.abs(opt.cost_history[:, 0] - r["hist_cost"][:, 0]).max() <= 1e-4 * np.abs(r["hist_cost"][:, 0]).max()
+    assert np.abs(opt.min_cost - r["min_cost"]).max() <= 2e-3 * np.abs(r["min_cost"]).max()

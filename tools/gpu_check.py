@@ -68,8 +68,8 @@ def main():
         t0 = time.time(); p = problems.car_batch(B, 200); t1 = time.time()
         car = cf.demo_car_system()
         ref = None
-        for L, A in ((2, 8), (4, 4), (8, 2)):
-            for ns in (1, 2, 3, 4, 8):
+        for L, A in ((2, 8), (1, 16)):
+            for ns in (1, 2, 3, 4):
                 opt = iterative_LQR(car, p["target_states"], car.dt, lanes_per_problem=L, alphas_per_lane=A, n_streams=ns)
                 opt.inputs = p["init_inputs"].copy(); opt.states = p["init_states"].copy()
                 dev = opt.upload(); torch.cuda.synchronize()
