@@ -17,6 +17,7 @@ struct ilqr_handle {
     // ilqr_solve may split the batch into parts that run on streams of their own, so that one
     // part's arithmetic-bound line search overlaps another part's bandwidth-bound passes
     int n_parts = 1;
+    int repack_every = 0;   // 0: no compaction
     bool streams_ready = false;
     hipStream_t part_stream[MAX_PARTS] = {};
     hipEvent_t fork_event = nullptr, join_event[MAX_PARTS] = {};
@@ -61,6 +62,95 @@ template <bool TO_TILED> static int relayout(const void *src, void *dst, int B, 
     else
         return ILQR_ERR_INVALID;
     return hip_rc(hipGetLastError());
+}
+
+// ---- active-set compaction (see kernels.hpp) --------------------------------------------
+struct PartState {
+    HostCtx ctx;      // launch context of this part (tile range [first, first + count))
+    int index = 0;    // part number
+    bool packed = false;
+    int parity = 0;   // working set in use once packed
+};
+
+template <typename T>
+static hipError_t repack_launch(ilqr_handle *h, PartState &ps, bool final_pass, hipStream_t s) {
+    const ilqr_desc &d = h->ctx.d;
+    const ilqr_buffers &b = h->ctx.b;
+    const WorkLayout wl = work_layout(d, true);
+    char *work = (char *)b.work;
+    const int N = d.N, T1 = d.N - 1, n = d.n, m = d.m;
+    const bool barrier = (d.constraint_mode & ILQR_CONSTR_BARRIER) != 0;
+    const size_t tile0 = (size_t)(ps.ctx.first / TILE);
+    const int ntiles = (ps.ctx.count + TILE - 1) / TILE;
+    const int q = ps.packed ? 1 - ps.parity : 0;
+    auto part_rel = [&](const void *base, int rows) -> T * { return base ? (T *)base + tile0 * (size_t)rows * TILE : nullptr; };
+    auto set_ptr = [&](int set, int which, int rows) -> T * { return part_rel(work + wl.set[set][which], rows); };
+    int32_t *map_new = (int32_t *)(work + wl.map[q]) + ps.ctx.first;
+    int32_t *tile_count = (int32_t *)(work + wl.tile_count) + tile0;
+    int32_t *tile_offset = (int32_t *)(work + wl.tile_offset) + tile0;
+    int32_t *nslots_new = (int32_t *)(work + wl.nslots) + ps.index * 2 + q;
+    const int32_t *map_old = ps.ctx.ws.slot2orig, *nslots_old = ps.ctx.ws.nslots;
+
+    if (!final_pass) {
+        hipLaunchKernelGGL(repack_count_kernel, dim3(ntiles), dim3(64), 0, s, map_old, nslots_old, ps.ctx.count, ps.ctx.first,
+                           b.converged, tile_count);
+        hipLaunchKernelGGL(repack_scan_kernel, dim3(1), dim3(1024), 0, s, (const int32_t *)tile_count, tile_offset, ntiles, nslots_new);
+    }
+    RepackArgs<T> a;
+    a.narr = 0;
+    auto add = [&](const void *src, T *dst_active, T *dst_retire, int rows) {
+        if (!dst_active && !dst_retire) return;
+        a.arr[a.narr].src = (const T *)src;
+        a.arr[a.narr].dst_active = dst_active;
+        a.arr[a.narr].dst_retire = dst_retire;
+        a.arr[a.narr].rows = rows;
+        ++a.narr;
+    };
+    const bool pk = ps.packed;
+    // current arrays: the caller's buffers until the first repack, a working set afterwards
+    const void *Xc = pk ? ps.ctx.ws.X : part_rel(b.X, N * n), *Uc = pk ? ps.ctx.ws.U : part_rel(b.U, T1 * m);
+    const void *Rc = pk ? ps.ctx.ws.Xref : part_rel(b.Xref, N * n);
+    const void *Kc = pk ? ps.ctx.ws.K : part_rel(b.K, T1 * m * n), *kc = pk ? ps.ctx.ws.k : part_rel(b.k, T1 * m);
+    const void *Cc = pk ? ps.ctx.ws.centers : part_rel(b.centers, N * 2), *Dc = pk ? ps.ctx.ws.radius : part_rel(b.radius, N);
+    // retired problems go to their own place in the caller's buffers; before the first repack
+    // they are there already
+    add(Xc, final_pass ? nullptr : set_ptr(q, 0, N * n), pk ? (T *)b.X : nullptr, N * n);
+    add(Uc, final_pass ? nullptr : set_ptr(q, 1, T1 * m), pk ? (T *)b.U : nullptr, T1 * m);
+    add(Rc, final_pass ? nullptr : set_ptr(q, 2, N * n), nullptr, N * n);
+    if (barrier) {
+        add(Cc, final_pass ? nullptr : set_ptr(q, 3, N * 2), nullptr, N * 2);
+        add(Dc, final_pass ? nullptr : set_ptr(q, 4, N), nullptr, N);
+    }
+    add(Kc, nullptr, pk ? (T *)b.K : nullptr, T1 * m * n);
+    add(kc, nullptr, pk ? (T *)b.k : nullptr, T1 * m);
+    a.slot2orig_old = map_old;
+    a.slot2orig_new = map_new;
+    a.nslots_old = nslots_old;
+    a.tile_offset = tile_offset;
+    a.converged = b.converged;
+    a.B = ps.ctx.count;
+    a.first = ps.ctx.first;
+    a.retire_all = final_pass ? 1 : 0;
+    if (a.narr > 0) hipLaunchKernelGGL((repack_move_kernel<T>), dim3(ntiles), dim3(64), 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || final_pass) return e;
+    ps.ctx.ws.X = set_ptr(q, 0, N * n);
+    ps.ctx.ws.U = set_ptr(q, 1, T1 * m);
+    ps.ctx.ws.Xref = set_ptr(q, 2, N * n);
+    ps.ctx.ws.centers = barrier ? set_ptr(q, 3, N * 2) : nullptr;
+    ps.ctx.ws.radius = barrier ? set_ptr(q, 4, N) : nullptr;
+    ps.ctx.ws.K = part_rel(work + wl.Kw, T1 * m * n);
+    ps.ctx.ws.k = part_rel(work + wl.kw, T1 * m);
+    ps.ctx.ws.slot2orig = map_new;
+    ps.ctx.ws.nslots = nslots_new;
+    ps.packed = true;
+    ps.parity = q;
+    return hipSuccess;
+}
+
+static int repack(ilqr_handle *h, PartState &ps, bool final_pass, hipStream_t s) {
+    if (final_pass && !ps.packed) return ILQR_OK; // everything is in the caller's buffers already
+    return hip_rc(h->ctx.d.dtype == ILQR_F64 ? repack_launch<double>(h, ps, final_pass, s) : repack_launch<float>(h, ps, final_pass, s));
 }
 
 extern "C" {
@@ -139,6 +229,9 @@ int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
         if (parts == 0) parts = 1;
         if (parts > tiles) parts = tiles;
         h->n_parts = parts;
+        // active-set compaction is opt-in: results are bit-identical with and without it, and
+        // at B = 65536 Car problems its copies currently cost about what it saves
+        h->repack_every = d.repack_every > 0 ? d.repack_every : 0;
     }
     *out = h;
     return ILQR_OK;
@@ -156,16 +249,8 @@ void ilqr_destroy(ilqr_handle *h) {
     delete h;
 }
 
-static size_t jtry_bytes(const ilqr_handle *h) {
-    const size_t e = h->ctx.d.dtype == ILQR_F64 ? 8 : 4;
-    return ((size_t)h->ctx.d.B * e + 255) & ~(size_t)255;
-}
-
-static size_t flag_bytes(const ilqr_handle *h) { return ((size_t)h->ctx.d.B * 4 + 255) & ~(size_t)255; }
-
-// layout of `work`: [ trial cost of the accepted step size, per problem | slow-trigonometry flag,
-// per problem (int32) | 256 B of counters ]
-size_t ilqr_workspace_bytes(const ilqr_handle *h) { return h ? jtry_bytes(h) + flag_bytes(h) + 256 : 0; }
+// layout of `work`: see work_layout() in host.hpp
+size_t ilqr_workspace_bytes(const ilqr_handle *h) { return h ? work_layout(h->ctx.d, h->repack_every > 0).total : 0; }
 
 int32_t ilqr_num_alphas(const ilqr_handle *h) { return h ? h->ctx.n_alphas : 0; }
 
@@ -212,68 +297,72 @@ int ilqr_forward(ilqr_handle *h, int32_t iteration, void *stream) {
     return ilqr_forward_commit(h, iteration, stream);
 }
 
-static int solve_part(ilqr_handle *h, const HostCtx &c, int max_iter, hipStream_t s) {
-    int rc = hip_rc(h->ops->cost(c, 0, s));
-    for (int it = 0; it < max_iter && rc == ILQR_OK; ++it) {
-        rc = hip_rc(h->ops->backward(c, 0, s));
-        if (rc == ILQR_OK) rc = hip_rc(h->ops->evaluate(c, 0, s));
-        if (rc == ILQR_OK) rc = hip_rc(h->ops->commit(c, it, s));
-    }
-    return rc;
-}
-
 int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream) {
     REQUIRE_BOUND(h);
     if (max_iter < 0) return ILQR_ERR_INVALID;
     hipStream_t user = (hipStream_t)stream;
-    if (h->n_parts <= 1) return solve_part(h, h->ctx, max_iter, user);
-    // fork: every part waits for the caller's stream, runs its whole solve on a stream of its
-    // own (parts are disjoint tile ranges, so they never touch the same memory), and the
-    // caller's stream waits for all parts.  No host synchronisation.
-    if (!h->streams_ready) {
-        hipError_t e = hipEventCreateWithFlags(&h->fork_event, hipEventDisableTiming);
-        for (int s = 0; s < h->n_parts && e == hipSuccess; ++s) {
-            e = hipStreamCreateWithFlags(&h->part_stream[s], hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&h->join_event[s], hipEventDisableTiming);
+    const int np = h->n_parts;
+    hipError_t e = hipSuccess;
+    if (np > 1) {
+        // fork: every part waits for the caller's stream, runs its whole solve on a stream of its
+        // own (parts are disjoint tile ranges, so they never touch the same memory), and the
+        // caller's stream waits for all parts.  No host synchronisation.
+        if (!h->streams_ready) {
+            e = hipEventCreateWithFlags(&h->fork_event, hipEventDisableTiming);
+            for (int s = 0; s < np && e == hipSuccess; ++s) {
+                e = hipStreamCreateWithFlags(&h->part_stream[s], hipStreamNonBlocking);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&h->join_event[s], hipEventDisableTiming);
+            }
+            if (e != hipSuccess) return hip_rc(e);
+            h->streams_ready = true;
         }
+        e = hipEventRecord(h->fork_event, user);
         if (e != hipSuccess) return hip_rc(e);
-        h->streams_ready = true;
     }
-    hipError_t e = hipEventRecord(h->fork_event, user);
-    if (e != hipSuccess) return hip_rc(e);
     const int tiles = (h->ctx.d.B + TILE - 1) / TILE;
     int rc = ILQR_OK;
-    // launch order: iteration-major across parts, so that the parts advance together and the
-    // hardware queues always hold kernels of different phases
-    HostCtx part[MAX_PARTS];
-    for (int s = 0; s < h->n_parts; ++s) {
-        part[s] = h->ctx;
-        const int t0 = (int)((long)tiles * s / h->n_parts), t1 = (int)((long)tiles * (s + 1) / h->n_parts);
-        part[s].first = t0 * TILE;
+    PartState part[MAX_PARTS];
+    hipStream_t st[MAX_PARTS];
+    for (int s = 0; s < np; ++s) {
+        part[s].ctx = h->ctx;
+        part[s].index = s;
+        const int t0 = (int)((long)tiles * s / np), t1 = (int)((long)tiles * (s + 1) / np);
+        part[s].ctx.first = t0 * TILE;
         const int end = t1 * TILE < h->ctx.d.B ? t1 * TILE : h->ctx.d.B;
-        part[s].count = end - part[s].first;
-        e = hipStreamWaitEvent(h->part_stream[s], h->fork_event, 0);
-        if (e != hipSuccess) return hip_rc(e);
-        rc = hip_rc(h->ops->cost(part[s], 0, h->part_stream[s]));
+        part[s].ctx.count = end - part[s].ctx.first;
+        st[s] = np > 1 ? h->part_stream[s] : user;
+        if (np > 1) {
+            e = hipStreamWaitEvent(st[s], h->fork_event, 0);
+            if (e != hipSuccess) return hip_rc(e);
+        }
+        rc = hip_rc(h->ops->cost(part[s].ctx, 0, st[s]));
         if (rc != ILQR_OK) return rc;
     }
-    // The line search is arithmetic-bound, the backward pass and the commit are bandwidth-bound.
-    // A token (an event chain) lets only one part run its line search at a time, which pushes the
-    // parts into opposite phases: while one computes, the others stream.
+    // Launch order is iteration-major across parts.  The line search is arithmetic-bound, the
+    // backward pass and the commit are bandwidth-bound; a token (an event chain) lets only one
+    // part run its line search at a time, which pushes the parts into opposite phases.
     int prev = -1;
     for (int it = 0; it < max_iter && rc == ILQR_OK; ++it)
-        for (int s = 0; s < h->n_parts && rc == ILQR_OK; ++s) {
-            rc = hip_rc(h->ops->backward(part[s], 0, h->part_stream[s]));
-            if (rc == ILQR_OK && prev >= 0) rc = hip_rc(hipStreamWaitEvent(h->part_stream[s], h->join_event[prev], 0));
-            if (rc == ILQR_OK) rc = hip_rc(h->ops->evaluate(part[s], 0, h->part_stream[s]));
-            if (rc == ILQR_OK) rc = hip_rc(hipEventRecord(h->join_event[s], h->part_stream[s]));
-            prev = s;
-            if (rc == ILQR_OK) rc = hip_rc(h->ops->commit(part[s], it, h->part_stream[s]));
+        for (int s = 0; s < np && rc == ILQR_OK; ++s) {
+            if (h->repack_every > 0 && it > 0 && it % h->repack_every == 0) rc = repack(h, part[s], false, st[s]);
+            if (rc == ILQR_OK) rc = hip_rc(h->ops->backward(part[s].ctx, 0, st[s]));
+            if (np > 1) {
+                if (rc == ILQR_OK && prev >= 0) rc = hip_rc(hipStreamWaitEvent(st[s], h->join_event[prev], 0));
+                if (rc == ILQR_OK) rc = hip_rc(h->ops->evaluate(part[s].ctx, 0, st[s]));
+                if (rc == ILQR_OK) rc = hip_rc(hipEventRecord(h->join_event[s], st[s]));
+                prev = s;
+            } else if (rc == ILQR_OK) {
+                rc = hip_rc(h->ops->evaluate(part[s].ctx, 0, st[s]));
+            }
+            if (rc == ILQR_OK) rc = hip_rc(h->ops->commit(part[s].ctx, it, st[s]));
         }
-    for (int s = 0; s < h->n_parts; ++s) {
-        e = hipEventRecord(h->join_event[s], h->part_stream[s]);
-        if (e == hipSuccess) e = hipStreamWaitEvent(user, h->join_event[s], 0);
-        if (e != hipSuccess && rc == ILQR_OK) rc = hip_rc(e);
+    for (int s = 0; s < np; ++s) {
+        if (rc == ILQR_OK) rc = repack(h, part[s], true, st[s]); // retire what is still in a working set
+        if (np > 1) {
+            e = hipEventRecord(h->join_event[s], st[s]);
+            if (e == hipSuccess) e = hipStreamWaitEvent(user, h->join_event[s], 0);
+            if (e != hipSuccess && rc == ILQR_OK) rc = hip_rc(e);
+        }
     }
     return rc;
 }
@@ -291,7 +380,7 @@ int ilqr_active_count(ilqr_handle *h, void *stream, int32_t *out) {
     REQUIRE_BOUND(h);
     if (!out) return ILQR_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    int32_t *counter = (int32_t *)((char *)h->ctx.b.work + jtry_bytes(h) + flag_bytes(h));
+    int32_t *counter = (int32_t *)((char *)h->ctx.b.work + work_layout(h->ctx.d, false).counters);
     hipError_t e = hipMemsetAsync(counter, 0, sizeof(int32_t), s);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(count_active_kernel, dim3((h->ctx.d.B + 255) / 256), dim3(256), 0, s, h->ctx.b.converged, h->ctx.d.B, counter);

@@ -18,7 +18,60 @@ struct HostCtx {
     // a launch may cover only the problems [first, first + count) of the bound batch
     // (first is a multiple of 64 so that the part starts on a tile boundary)
     int first = 0, count = 0;
+    // working set of ilqr_solve's active-set compaction: when `slot2orig` is set, the tiled
+    // arrays below replace the bound ones (they are already relative to this part and hold
+    // *nslots problems in slot order) and the per-problem arrays are indexed through the map
+    struct WorkSet {
+        void *X = nullptr, *U = nullptr, *Xref = nullptr, *K = nullptr, *k = nullptr, *centers = nullptr, *radius = nullptr;
+        const int32_t *slot2orig = nullptr;
+        const int32_t *nslots = nullptr;
+    } ws;
 };
+
+// Layout of the caller-provided `work` buffer (byte offsets).  The first three regions always
+// exist; the rest only with active-set compaction.
+struct WorkLayout {
+    size_t jtry = 0, slow = 0, counters = 0;
+    size_t map[2] = {0, 0}, tile_count = 0, tile_offset = 0, nslots = 0;
+    size_t set[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}; // X, U, Xref, centers, radius of the two working sets
+    size_t Kw = 0, kw = 0;
+    size_t total = 0;
+};
+
+static inline WorkLayout work_layout(const ilqr_desc &d, bool compaction) {
+    WorkLayout w;
+    const size_t e = d.dtype == ILQR_F64 ? 8 : 4;
+    const size_t tiles = ((size_t)d.B + TILE - 1) / TILE, Bp = tiles * TILE;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return at;
+    };
+    w.jtry = take((size_t)d.B * e);
+    w.slow = take((size_t)d.B * 4);
+    w.counters = take(256);
+    if (compaction) {
+        const size_t N = d.N, T1 = d.N - 1, n = d.n, m = d.m;
+        const bool barrier = (d.constraint_mode & ILQR_CONSTR_BARRIER) != 0;
+        w.map[0] = take(Bp * 4);
+        w.map[1] = take(Bp * 4);
+        w.tile_count = take(tiles * 4);
+        w.tile_offset = take(tiles * 4);
+        w.nslots = take(256);
+        for (int q = 0; q < 2; ++q) {
+            w.set[q][0] = take(Bp * N * n * e);
+            w.set[q][1] = take(Bp * T1 * m * e);
+            w.set[q][2] = take(Bp * N * n * e);
+            w.set[q][3] = take(barrier ? Bp * N * 2 * e : 0);
+            w.set[q][4] = take(barrier ? Bp * N * e : 0);
+        }
+        w.Kw = take(Bp * T1 * m * n * e);
+        w.kw = take(Bp * T1 * m * e);
+    }
+    w.total = off;
+    return w;
+}
 
 typedef hipError_t (*launch_fn)(const HostCtx &, int it, hipStream_t);
 struct ModelOps {
@@ -38,29 +91,41 @@ template <typename T, int NX, int NU> static Params<T, NX, NU> make_params(const
     const ilqr_desc &d = c.d;
     const ilqr_buffers &b = c.b;
     const int N = d.N, T1 = d.N - 1;
-    const size_t tile0 = (size_t)(c.first / TILE), f = (size_t)c.first;
+    const bool packed = c.ws.slot2orig != nullptr;
+    // with a working set the per-problem arrays are indexed by the global problem index held in
+    // the slot map, so they are not offset by the part's first problem
+    const size_t tile0 = (size_t)(c.first / TILE), f = packed ? 0 : (size_t)c.first;
     auto tiled = [&](const void *base, int rows) -> T * {
         return base ? (T *)base + tile0 * (size_t)rows * TILE : nullptr;
     };
     auto flat = [&](auto *base) { return base ? base + f : base; };
-    p.X = tiled(b.X, N * NX);
-    p.U = tiled(b.U, T1 * NU);
-    p.Xref = tiled(b.Xref, N * NX);
-    p.K = tiled(b.K, T1 * NU * NX);
-    p.k = tiled(b.k, T1 * NU);
-    p.J = flat((T *)b.J);
-    p.Jtry = flat((T *)b.work);
-    {
-        const size_t e = sizeof(T);
-        const size_t jtry_bytes = ((size_t)d.B * e + 255) & ~(size_t)255;
-        p.slow_trig = flat((int32_t *)((char *)b.work + jtry_bytes));
+    const WorkLayout wl = work_layout(d, false);
+    if (packed) {
+        p.X = (T *)c.ws.X;
+        p.U = (T *)c.ws.U;
+        p.Xref = (const T *)c.ws.Xref;
+        p.K = (T *)c.ws.K;
+        p.k = (T *)c.ws.k;
+        p.centers = (const T *)c.ws.centers;
+        p.radius = (const T *)c.ws.radius;
+    } else {
+        p.X = tiled(b.X, N * NX);
+        p.U = tiled(b.U, T1 * NU);
+        p.Xref = tiled(b.Xref, N * NX);
+        p.K = tiled(b.K, T1 * NU * NX);
+        p.k = tiled(b.k, T1 * NU);
+        p.centers = tiled(b.centers, N * 2);
+        p.radius = tiled(b.radius, N);
     }
+    p.slot2orig = c.ws.slot2orig;
+    p.nslots = c.ws.nslots;
+    p.J = flat((T *)b.J);
+    p.Jtry = flat((T *)((char *)b.work + wl.jtry));
+    p.slow_trig = flat((int32_t *)((char *)b.work + wl.slow));
     p.converged = flat(b.converged);
     p.iters = flat(b.iters);
     p.alpha_idx = flat(b.alpha_idx);
     p.status = flat(b.status);
-    p.centers = tiled(b.centers, N * 2);
-    p.radius = tiled(b.radius, N);
     p.ltvA = (const T *)b.ltv_A;
     p.ltvB = (const T *)b.ltv_B;
     p.hist_cost = flat((T *)b.hist_cost);

@@ -102,6 +102,9 @@ template <typename T> __device__ __forceinline__ T *tile_ptr(T *base, int tile, 
 }
 
 // ---------------------------------------------------------------- parameters
+template <class P> __device__ __forceinline__ int slot_count(const P &p) { return p.nslots ? *p.nslots : p.B; }
+template <class P> __device__ __forceinline__ int orig_of(const P &p, int slot) { return p.slot2orig ? p.slot2orig[slot] : slot; }
+
 // Passed by value as the kernel argument.  Q2/R2/Qf2 are 2Q, 2R, 2Qf (exact
 // scalings) used by the quadratisation (ilqr.py:79-92).
 template <typename T, int NX, int NU> struct Params {
@@ -111,6 +114,11 @@ template <typename T, int NX, int NU> struct Params {
     T *J, *Jtry;
     int32_t *converged, *iters, *alpha_idx, *status;
     int32_t *slow_trig; // per problem: the evaluate kernel needed the library sine/cosine
+    // Active-set compaction (ilqr_solve only): the tiled trajectory arrays then hold `*nslots`
+    // problems in slot order and slot2orig[slot] is the problem's index in the per-problem arrays
+    // (J, converged, iters, alpha_idx, status, Jtry, slow_trig, history).  Both null otherwise.
+    const int32_t *slot2orig;
+    const int32_t *nslots;
     const T *centers, *radius;
     const T *ltvA, *ltvB;
     T *hist_cost;
@@ -746,9 +754,11 @@ template <typename T, class M, bool DIAG, int CONSTR, int PF>
 __global__ __launch_bounds__(64) void backward_kernel(Params<T, M::NX, M::NU> p) {
     constexpr int NX = M::NX, NU = M::NU;
     const int b0 = blockIdx.x * 64 + threadIdx.x;
-    const bool valid = b0 < p.B;
-    const int b = valid ? b0 : p.B - 1;
-    const bool active = valid && p.converged[b] == 0;
+    const int nsl = slot_count(p);
+    if (nsl <= 0) return;
+    const bool valid = b0 < nsl;
+    const int o = orig_of(p, valid ? b0 : nsl - 1);
+    const bool active = valid && p.converged[o] == 0;
     if (__ballot(active) == 0ull) return;
     const int T1 = p.N - 1;
     constexpr bool BARRIER_ = (CONSTR & 2) != 0;
@@ -767,7 +777,7 @@ __global__ __launch_bounds__(64) void backward_kernel(Params<T, M::NX, M::NU> p)
     // that did not need either get the same bits as before)
     if (__ballot(bad && active) != 0ull)
         status = backward_sweep<T, M, DIAG, CONSTR, 1, false>(p, Xt, Rt, Ut, Cp, Dp, Kp, kp, bad);
-    if (active && status != 0 && p.status) p.status[b] |= status;
+    if (active && status != 0 && p.status) p.status[o] |= status;
 }
 
 // ---------------------------------------------------------------- rollout step
@@ -912,12 +922,15 @@ __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T,
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int pl = lane / L, al = lane % L;
     const int b0 = wave * PPW + pl;
-    const bool valid = b0 < p.B;
-    const int b = valid ? b0 : p.B - 1;
-    const bool active = valid && p.converged[b] == 0;
+    const int nsl = slot_count(p);
+    if (nsl <= 0) return;
+    const bool valid = b0 < nsl;
+    const int b = valid ? b0 : nsl - 1;
+    const int o = orig_of(p, b);
+    const bool active = valid && p.converged[o] == 0;
     if (__ballot(active) == 0ull) return;
     const int T1 = p.N - 1;
-    const T Jcur = p.J[b];
+    const T Jcur = p.J[o];
     const int tile = b >> 6, ln = b & 63;
     const T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
     const T *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
@@ -935,9 +948,9 @@ __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T,
     const bool wave_bad = __ballot(bad && active) != 0ull;
     if (wave_bad) evaluate_rounds<T, M, DIAG, BARRIER, L, A, false>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, best, best_cost, bad);
     if (active && al == 0) {
-        p.alpha_idx[b] = (best == 0x7fffffff) ? -1 : best;
-        p.Jtry[b] = best_cost;
-        p.slow_trig[b] = wave_bad ? 1 : 0;
+        p.alpha_idx[o] = (best == 0x7fffffff) ? -1 : best;
+        p.Jtry[o] = best_cost;
+        p.slow_trig[o] = wave_bad ? 1 : 0;
     }
 }
 
@@ -995,8 +1008,10 @@ template <typename T, class M, int PF>
 __global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, int it) {
     constexpr int NX = M::NX, NU = M::NU;
     const int b0 = blockIdx.x * 64 + threadIdx.x;
-    const bool valid = b0 < p.B;
-    const int b = valid ? b0 : p.B - 1;
+    const int nsl = slot_count(p);
+    if (nsl <= 0) return;
+    const bool valid = b0 < nsl;
+    const int b = orig_of(p, valid ? b0 : nsl - 1); // index into the per-problem arrays
     const bool active = valid && p.converged[b] == 0;
     if (__ballot(active) == 0ull) return;
     const int T1 = p.N - 1;
@@ -1030,6 +1045,107 @@ __global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, i
         commit_sweep<T, M, PF, true>(p, Xt, Ut, Kp, kp, alpha, roll);
     else
         commit_sweep<T, M, 1, false>(p, Xt, Ut, Kp, kp, alpha, roll);
+}
+
+// ---------------------------------------------------------------- active-set compaction
+// Converged problems stop costing time only when a whole 64-problem tile is converged, which
+// is rare because problems converge independently.  ilqr_solve therefore repacks every few
+// iterations: the still-active problems of the current working set are copied, in order, into
+// dense tiles of a second working set, and the problems that converged since the last repack
+// are retired, i.e. copied to their place in the caller's buffers.  Three tiny kernels build
+// the slot map; one streaming kernel moves the rows.
+
+// one wave per tile of the current working set: number of active problems in the tile
+static __global__ __launch_bounds__(64) void repack_count_kernel(const int32_t *slot2orig, const int32_t *nslots, int B, int first,
+                                                          const int32_t *converged, int32_t *tile_count) {
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    const int nsl = nslots ? *nslots : B;
+    const bool valid = s < nsl;
+    const int o = valid ? (slot2orig ? slot2orig[s] : s + first) : 0;
+    const bool act = valid && converged[o] == 0;
+    const unsigned long long m = __ballot(act);
+    if (threadIdx.x == 0) tile_count[blockIdx.x] = (int)__popcll(m);
+}
+
+// one workgroup: exclusive prefix sum of the tile counts, total -> *nslots_new
+static __global__ __launch_bounds__(1024) void repack_scan_kernel(const int32_t *tile_count, int32_t *tile_offset, int ntiles,
+                                                           int32_t *nslots_new) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (ntiles + 1023) / 1024;
+    const int lo = tid * per, hi = min(lo + per, ntiles);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += tile_count[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan of the partial sums
+        int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = tid ? part[tid - 1] : 0;
+    for (int i = lo; i < hi; ++i) {
+        tile_offset[i] = run;
+        run += tile_count[i];
+    }
+    if (tid == 1023) *nslots_new = part[1023];
+}
+
+template <typename T> struct RepackArray {
+    const T *src;   // current working set, slot order
+    T *dst_active;  // next working set, slot order (null: array is not carried over, e.g. the gains)
+    T *dst_retire;  // caller's buffer, problem order (null: the data is already in place there)
+    int rows;       // values per problem
+};
+template <typename T> struct RepackArgs {
+    RepackArray<T> arr[7];
+    int narr;
+    const int32_t *slot2orig_old; // null: identity
+    int32_t *slot2orig_new;
+    const int32_t *nslots_old;    // null: B
+    const int32_t *tile_offset;
+    const int32_t *converged;     // per problem, global index
+    int B;                        // problems of this part (slots before the first repack)
+    int first;                    // global index of the part's first problem
+    int retire_all;               // final pass: every slot is retired, none carried over
+};
+
+// one wave per tile of the current working set; streams every row of the tile once
+template <typename T> __global__ __launch_bounds__(64) void repack_move_kernel(RepackArgs<T> a) {
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    const int s = tile * 64 + lane;
+    const int nsl = a.nslots_old ? *a.nslots_old : a.B;
+    if (tile * 64 >= nsl) return;
+    const bool valid = s < nsl;
+    const int o = valid ? (a.slot2orig_old ? a.slot2orig_old[s] : s + a.first) : 0;
+    const bool act = valid && !a.retire_all && a.converged[o] == 0;
+    const bool ret = valid && !act;
+    const unsigned long long m = __ballot(act);
+    const int ns = act ? a.tile_offset[tile] + (int)__popcll(m & ((1ull << lane) - 1ull)) : 0;
+    if (act) a.slot2orig_new[ns] = o;
+    for (int q = 0; q < a.narr; ++q) {
+        const RepackArray<T> r = a.arr[q];
+        const T *src = r.src + (size_t)tile * r.rows * TILE + lane;
+        T *da = (act && r.dst_active) ? r.dst_active + (size_t)(ns >> 6) * r.rows * TILE + (ns & 63) : nullptr;
+        T *dr = (ret && r.dst_retire) ? r.dst_retire + (size_t)(o >> 6) * r.rows * TILE + (o & 63) : nullptr;
+        T *dst = da ? da : dr;
+        if (__ballot(dst != nullptr) == 0ull) continue;
+        int i = 0;
+        for (; i + 4 <= r.rows; i += 4) {
+            T v0 = src[(i + 0) * TILE], v1 = src[(i + 1) * TILE], v2 = src[(i + 2) * TILE], v3 = src[(i + 3) * TILE];
+            if (dst) {
+                dst[(i + 0) * TILE] = v0;
+                dst[(i + 1) * TILE] = v1;
+                dst[(i + 2) * TILE] = v2;
+                dst[(i + 3) * TILE] = v3;
+            }
+        }
+        for (; i < r.rows; ++i) {
+            T v = src[i * TILE];
+            if (dst) dst[i * TILE] = v;
+        }
+    }
 }
 
 // ---------------------------------------------------------------- layout conversion

@@ -84,6 +84,9 @@ typedef struct ilqr_desc {
     int32_t alphas_per_lane;   /* step sizes each lane rolls out per round (1,2,4,8,16); 0 = auto */
     int32_t n_streams;         /* ilqr_solve splits the batch into this many tile ranges, each on a stream of
                                   its own, so phases of different parts overlap (1..8); 0 = auto */
+    int32_t repack_every;      /* ilqr_solve compacts the still-active problems into dense tiles every this many
+                                  iterations (needs the larger workspace, see ilqr_workspace_bytes); <= 0 = never */
+    int32_t reserved1;
     double dt;               /* system.dt (systems.py:30); the solver's own dt argument is unused (ilqr.py:20) */
     double lm_parameter;     /* ilqr.py:30, added to Vxx (ilqr.py:95) */
     double alpha_floor;      /* 1e-4 (ilqr.py:71) or alpha_terminal (cilqr.py:41) */

@@ -189,6 +189,47 @@ def test_shard_invariance_is_bitwise(ilqr_cls):
         assert np.array_equal(np.concatenate([getattr(a, key), getattr(b, key)]), getattr(full, key)), key
 
 
+def test_compaction_and_streams_do_not_change_a_bit(ilqr_cls):
+    """ilqr_solve may repack the still-active problems into dense tiles every few iterations and
+    may split the batch over several streams; both are pure scheduling.  States, inputs, gains,
+    costs, histories and flags must equal the plain single-stream run bit for bit (ragged batch,
+    so that the last tile is partial and parts are uneven)."""
+    from ilqr_amd import problems
+    p = problems.car_batch(333, 90)
+    ref = _solve_batch(ilqr_cls, p, repack_every=-1, n_streams=1)
+    Kr, kr = ref.K.copy(), ref.k.copy()
+    assert ref.converge.any() and not ref.converge.all()     # both kinds of problems present
+    for every, ns in ((1, 1), (3, 1), (4, 2), (2, 3), (7, 1)):
+        o = _solve_batch(ilqr_cls, p, repack_every=every, n_streams=ns)
+        for key in ("states", "inputs", "min_cost", "iterations", "converge", "status"):
+            assert np.array_equal(getattr(o, key), getattr(ref, key)), (every, ns, key)
+        assert np.array_equal(o.alpha_history, ref.alpha_history)
+        assert np.array_equal(o.cost_history, ref.cost_history, equal_nan=True)
+        assert np.array_equal(o.K, Kr) and np.array_equal(o.k, kr), (every, ns)
+
+
+def test_compaction_with_barrier_mode(oracle):
+    from ilqr_amd import problems
+    from ilqr_amd.cilqr import iterative_LQR as CILQR
+    from ilqr_amd.constraints import BubbleConstraint
+    car, tg, ui = cilqr_problem(80, 4)
+    B = 70
+    tgs = np.stack([tg + 0.05 * b for b in range(B)])
+    centers, radius, vb = problems.bubbles_for(tgs, radius=6.0, vel_bounds=(-1.0, 14.0))
+    con = BubbleConstraint(80)
+    con.setup(centers, radius, vb)
+    outs = []
+    for every in (-1, 2):
+        opt = CILQR(car, tgs, car.dt, history=True, repack_every=every)
+        opt.inputs = np.stack([ui] * B)
+        opt.maxIter = 20
+        opt.set_barrier(con, mu=50.0, delta=0.5)
+        opt()
+        outs.append(opt)
+    assert np.array_equal(outs[0].states, outs[1].states) and np.array_equal(outs[0].min_cost, outs[1].min_cost)
+    assert np.array_equal(outs[0].cost_history, outs[1].cost_history, equal_nan=True)
+
+
 # --------------------------------------------------------------------------- edge cases
 def test_edge_shapes_and_flags(ilqr_cls, oracle):
     from ilqr_amd import problems

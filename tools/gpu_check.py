@@ -68,9 +68,9 @@ def main():
         t0 = time.time(); p = problems.car_batch(B, 200); t1 = time.time()
         car = cf.demo_car_system()
         ref = None
-        for L, A in ((2, 8), (1, 16)):
-            for ns in (1, 2, 3, 4):
-                opt = iterative_LQR(car, p["target_states"], car.dt, lanes_per_problem=L, alphas_per_lane=A, n_streams=ns)
+        for L, A, ns, rep in ((2, 8, 1, -1), (2, 8, 1, 2), (2, 8, 1, 3), (2, 8, 1, 4), (2, 8, 1, 6), (2, 8, 2, -1), (2, 8, 2, 3), (2, 8, 2, 4), (2, 8, 2, 6)):
+            if True:
+                opt = iterative_LQR(car, p["target_states"], car.dt, lanes_per_problem=L, alphas_per_lane=A, n_streams=ns, repack_every=rep)
                 opt.inputs = p["init_inputs"].copy(); opt.states = p["init_states"].copy()
                 dev = opt.upload(); torch.cuda.synchronize()
                 X0, U0 = dev.X.clone(), dev.U.clone()
@@ -82,7 +82,7 @@ def main():
                 J = dev.J.cpu().numpy()
                 if ref is None:
                     ref = J
-                print(f"B={B} L={L} A={A} streams={ns}: solve {1e3 * best:.1f} ms -> {B / best:.0f} solves/s, same bits as first: {np.array_equal(J, ref)}")
+                print(f"B={B} L={L} A={A} streams={ns} repack={rep}: solve {1e3 * best:.1f} ms -> {B / best:.0f} solves/s, same bits as first: {np.array_equal(J, ref)}")
 
 
 if __name__ == "__main__":
