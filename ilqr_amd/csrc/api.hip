@@ -203,7 +203,7 @@ int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
     }
     {
         const int key = L * 100 + A;
-        const int ok[] = {1601, 802, 404, 208, 116, 801, 401, 104, 204};
+        const int ok[] = {1601, 802, 404, 208, 116, 801, 402, 204, 108, 401, 104};
         bool found = false;
         for (int v : ok) found = found || (v == key);
         if (!found) return ILQR_ERR_UNSUPPORTED;

@@ -28,10 +28,10 @@ struct HostCtx {
     } ws;
 };
 
-// Layout of the caller-provided `work` buffer (byte offsets).  The first three regions always
+// Layout of the caller-provided `work` buffer (byte offsets).  The first five regions always
 // exist; the rest only with active-set compaction.
 struct WorkLayout {
-    size_t jtry = 0, slow = 0, counters = 0;
+    size_t jtry = 0, slow = 0, counters = 0, list = 0, list_count = 0;
     size_t map[2] = {0, 0}, tile_count = 0, tile_offset = 0, nslots = 0;
     size_t set[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}; // X, U, Xref, centers, radius of the two working sets
     size_t Kw = 0, kw = 0;
@@ -51,6 +51,8 @@ static inline WorkLayout work_layout(const ilqr_desc &d, bool compaction) {
     w.jtry = take((size_t)d.B * e);
     w.slow = take((size_t)d.B * 4);
     w.counters = take(256);
+    w.list = take(Bp * 4);          // line-search stage two: slots still without a winner
+    w.list_count = take(tiles * 4); // their number, one counter per possible first tile of a part
     if (compaction) {
         const size_t N = d.N, T1 = d.N - 1, n = d.n, m = d.m;
         const bool barrier = (d.constraint_mode & ILQR_CONSTR_BARRIER) != 0;
@@ -119,6 +121,8 @@ template <typename T, int NX, int NU> static Params<T, NX, NU> make_params(const
     }
     p.slot2orig = c.ws.slot2orig;
     p.nslots = c.ws.nslots;
+    p.list = (int32_t *)((char *)b.work + wl.list) + c.first;
+    p.list_count = (int32_t *)((char *)b.work + wl.list_count) + tile0;
     p.J = flat((T *)b.J);
     p.Jtry = flat((T *)((char *)b.work + wl.jtry));
     p.slow_trig = flat((int32_t *)((char *)b.work + wl.slow));
@@ -207,12 +211,30 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
         if (mode == 1) return backward_c<1>(c, s);
         return hipErrorInvalidValue;
     }
+    // Line search in two stages: the L*A first candidates for every active problem, then the
+    // rest for the few problems that found no winner among them (kernels.hpp, evaluate_kernel)
     template <bool BARRIER, int L, int A> static hipError_t eval_la(const HostCtx &c, hipStream_t s) {
         auto p = make_params<T, NX, NU>(c);
-        const int ppw = 64 / L;                        // problems per wave
-        const long waves = ((long)c.count + ppw - 1) / ppw;
-        const int blocks = (int)((waves + 3) / 4);     // 4 waves per workgroup
-        hipLaunchKernelGGL((evaluate_kernel<T, M, DIAG, BARRIER, L, A>), dim3(blocks), dim3(256), 0, s, p);
+        const int first_end = c.n_alphas < L * A ? c.n_alphas : L * A;
+        const bool two = first_end < c.n_alphas;
+        if (two) {
+            hipError_t e = hipMemsetAsync(p.list_count, 0, sizeof(int32_t), s);
+            if (e != hipSuccess) return e;
+        }
+        {
+            const int ppw = 64 / L;                    // problems per wave
+            const long waves = ((long)c.count + ppw - 1) / ppw;
+            const int blocks = (int)((waves + 3) / 4); // 4 waves per workgroup
+            hipLaunchKernelGGL((evaluate_kernel<T, M, DIAG, BARRIER, L, A>), dim3(blocks), dim3(256), 0, s, p, first_end);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess || !two) return e;
+        }
+        // the length of the list is only known on the device: the grid covers the worst case and
+        // the waves beyond the list leave at once
+        constexpr int L2 = M::NX > 8 ? 16 : 8;
+        const int ppw = 64 / L2;
+        const int blocks = (int)(((long)c.count + ppw - 1) / ppw); // one wave per workgroup
+        hipLaunchKernelGGL((evaluate_listed_kernel<T, M, DIAG, BARRIER, L2>), dim3(blocks), dim3(64), 0, s, p, first_end, c.n_alphas);
         return hipGetLastError();
     }
     template <bool BARRIER> static hipError_t eval_b(const HostCtx &c, hipStream_t s) {
@@ -233,9 +255,11 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
             case 116: return eval_la<BARRIER, 1, 16>(c, s);
             case 208: return eval_la<BARRIER, 2, 8>(c, s);
             case 801: return eval_la<BARRIER, 8, 1>(c, s);
+            case 402: return eval_la<BARRIER, 4, 2>(c, s);
+            case 204: return eval_la<BARRIER, 2, 4>(c, s);
+            case 108: return eval_la<BARRIER, 1, 8>(c, s);
             case 401: return eval_la<BARRIER, 4, 1>(c, s);
             case 104: return eval_la<BARRIER, 1, 4>(c, s);
-            case 204: return eval_la<BARRIER, 2, 4>(c, s);
             default: return hipErrorInvalidValue;
             }
         }

@@ -119,6 +119,10 @@ template <typename T, int NX, int NU> struct Params {
     // (J, converged, iters, alpha_idx, status, Jtry, slow_trig, history).  Both null otherwise.
     const int32_t *slot2orig;
     const int32_t *nslots;
+    // line-search stage two: slots that found no winner in stage one (the host zeroes the count
+    // before stage one, the stage-one kernel appends)
+    int32_t *list;
+    int32_t *list_count;
     const T *centers, *radius;
     const T *ltvA, *ltvB;
     T *hist_cost;
@@ -808,6 +812,42 @@ template <typename T, int NX, int NU> struct FwdRow { // rows of one step shared
     T K[NU][NX], k[NU], xp[NX], up[NU], xr[NX], cx, cy, rad;
 };
 
+// One time step of one line-search candidate: stage cost of (x, u_new) and the next state
+// (ilqr.py:54-63 with the cost of ilqr.py:36-43 accumulated on the way).
+template <typename T, class M, bool DIAG, bool BARRIER, bool FAST, class P>
+__device__ __forceinline__ void candidate_step(const P &p, int t, T alpha, const FwdRow<T, M::NX, M::NU> &r, T (&x)[M::NX], T &cost,
+                                               bool &bad) {
+    constexpr int NX = M::NX, NU = M::NU;
+    T e[NX], un[NU], xn[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) e[i] = x[i] - r.xr[i];
+    control_update<T, M>(p, alpha, x, r.xp, r.up, r.K, r.k, un);
+    T stage = quad_<T, NX, DIAG>(p.Q, e) + quad_<T, NU, DIAG>(p.R, un);
+    if (BARRIER && t > 0) {
+        T dlx[NX], dlxx[NX][NX];
+        stage += barrier_terms<T, NX, false>(p, x, r.cx, r.cy, r.rad, dlx, dlxx);
+    }
+    cost += stage;
+    M::template step<FAST>(p, t, x, un, xn, bad);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = xn[i];
+}
+
+// Terminal term of a candidate (ilqr.py:44-45) added to its accumulated stage costs.
+template <typename T, class M, bool DIAG, bool BARRIER, class P>
+__device__ __forceinline__ T candidate_total(const P &p, const T (&x)[M::NX], const T (&xr)[M::NX], T cx, T cy, T rad, T cost) {
+    constexpr int NX = M::NX;
+    T e[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) e[i] = x[i] - xr[i];
+    T term = quad_<T, NX, DIAG>(p.Qf, e);
+    if (BARRIER) {
+        T dlx[NX], dlxx[NX][NX];
+        term += barrier_terms<T, NX, false>(p, x, cx, cy, rad, dlx, dlxx);
+    }
+    return cost + term;
+}
+
 // ---------------------------------------------------------------- evaluate
 // L lanes per problem x A step sizes per lane = L*A candidates per round;
 // rounds continue (in increasing index order, so the largest improving step
@@ -815,8 +855,8 @@ template <typename T, int NX, int NU> struct FwdRow { // rows of one step shared
 // winner or the candidates are exhausted.
 template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool FAST, class P>
 __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T *Rt, const T *Ut, const T *Kp, const T *kp,
-                                                const T *Cp, const T *Dp, int al, bool active, T Jcur, int &best, T &best_cost,
-                                                bool &bad) {
+                                                const T *Cp, const T *Dp, int al, bool active, T Jcur, int base0, int end,
+                                                int &best, T &best_cost, bool &bad) {
     constexpr int NX = M::NX, NU = M::NU;
     const int T1 = p.N - 1;
     auto load_row = [&](int t, FwdRow<T, NX, NU> &r) {
@@ -842,8 +882,7 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
     };
     best = 0x7fffffff;
     best_cost = T(0);
-    T dlx[NX], dlxx[NX][NX];
-    for (int base = 0; base < p.n_alphas; base += L * A) {
+    for (int base = base0; base < end; base += L * A) {
         T x[A][NX], cost[A], alpha[A];
 #pragma unroll
         for (int j = 0; j < A; ++j) {
@@ -858,18 +897,7 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
             FwdRow<T, NX, NU> r = nxt;
             if (t + 1 < T1) load_row(t + 1, nxt);
 #pragma unroll
-            for (int j = 0; j < A; ++j) {
-                T e[NX], un[NU], xn[NX];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) e[i] = x[j][i] - r.xr[i];
-                control_update<T, M>(p, alpha[j], x[j], r.xp, r.up, r.K, r.k, un);
-                T stage = quad_<T, NX, DIAG>(p.Q, e) + quad_<T, NU, DIAG>(p.R, un);
-                if (BARRIER && t > 0) stage += barrier_terms<T, NX, false>(p, x[j], r.cx, r.cy, r.rad, dlx, dlxx);
-                cost[j] += stage;
-                M::template step<FAST>(p, t, x[j], un, xn, bad);
-#pragma unroll
-                for (int i = 0; i < NX; ++i) x[j][i] = xn[i];
-            }
+            for (int j = 0; j < A; ++j) candidate_step<T, M, DIAG, BARRIER, FAST>(p, t, alpha[j], r, x[j], cost[j], bad);
         }
         // terminal term (ilqr.py:44-45)
         T xr[NX], cx = T(0), cy = T(0), rad = T(0);
@@ -884,14 +912,9 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
         T cand_cost = T(0);
 #pragma unroll
         for (int j = A - 1; j >= 0; --j) {
-            T e[NX];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) e[i] = x[j][i] - xr[i];
-            T term = quad_<T, NX, DIAG>(p.Qf, e);
-            if (BARRIER) term += barrier_terms<T, NX, false>(p, x[j], cx, cy, rad, dlx, dlxx);
-            T c = cost[j] + term;
+            T c = candidate_total<T, M, DIAG, BARRIER>(p, x[j], xr, cx, cy, rad, cost[j]);
             const int a = base + al * A + j;
-            if (a < p.n_alphas && c < Jcur) { // strict test of ilqr.py:65; NaN never passes
+            if (a < end && c < Jcur) { // strict test of ilqr.py:65; NaN never passes
                 cand = a;
                 cand_cost = c;
             }
@@ -914,18 +937,24 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
     }
 }
 
+// The line search runs in two stages.  Stage one (evaluate_kernel) covers every active problem
+// and rolls out the candidates [0, end) - all of them if L*A >= n_alphas, else the first L*A,
+// which settle all but a few per cent of the problems.  A problem that found no winner among
+// them while candidates remain is appended to a device-side list; stage two
+// (evaluate_listed_kernel) walks that list with the remaining candidates.  Candidates are still
+// examined in increasing index order, so the result is that of the serial search.
 template <typename T, class M, bool DIAG, bool BARRIER, int L, int A>
-__global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T, M::NX, M::NU> p) {
+__global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T, M::NX, M::NU> p, int end) {
     constexpr int NX = M::NX, NU = M::NU;
     constexpr int PPW = 64 / L; // problems per wave
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int pl = lane / L, al = lane % L;
-    const int b0 = wave * PPW + pl;
+    const int g = wave * PPW + pl;
     const int nsl = slot_count(p);
-    if (nsl <= 0) return;
-    const bool valid = b0 < nsl;
-    const int b = valid ? b0 : nsl - 1;
+    if (wave * PPW >= nsl) return;
+    const bool valid = g < nsl;
+    const int b = valid ? g : nsl - 1; // slot
     const int o = orig_of(p, b);
     const bool active = valid && p.converged[o] == 0;
     if (__ballot(active) == 0ull) return;
@@ -942,15 +971,231 @@ __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T,
     int best;
     T best_cost;
     bool bad = false;
-    evaluate_rounds<T, M, DIAG, BARRIER, L, A, true>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, best, best_cost, bad);
+    evaluate_rounds<T, M, DIAG, BARRIER, L, A, true>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, 0, end, best, best_cost, bad);
     // an angle outside the fast trigonometric range anywhere in the wave: redo with the library
-    // routine and tell the commit kernel to do the same for these problems
-    const bool wave_bad = __ballot(bad && active) != 0ull;
-    if (wave_bad) evaluate_rounds<T, M, DIAG, BARRIER, L, A, false>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, best, best_cost, bad);
-    if (active && al == 0) {
-        p.alpha_idx[o] = (best == 0x7fffffff) ? -1 : best;
+    // routine; a problem one of whose lanes saw such an angle takes the redone result (and tells
+    // the commit kernel to use the library routine too), the others keep theirs, so a problem's
+    // result does not depend on which problems share its wave
+    bool pbad = bad;
+#pragma unroll
+    for (int w = 1; w < L; w <<= 1) pbad |= __shfl_xor((int)pbad, w) != 0;
+    if (__ballot(pbad && active) != 0ull) {
+        int best2;
+        T best_cost2;
+        bool bad2 = false;
+        evaluate_rounds<T, M, DIAG, BARRIER, L, A, false>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, 0, end, best2, best_cost2, bad2);
+        best = pbad ? best2 : best;
+        best_cost = pbad ? best_cost2 : best_cost;
+    }
+    const bool found = best != 0x7fffffff;
+    // stage two continues with the remaining candidates: one atomic per wave
+    const bool more = active && al == 0 && !found && end < p.n_alphas;
+    const unsigned long long mm = __ballot(more);
+    if (mm != 0ull) {
+        int at = 0;
+        if (lane == 0) at = atomicAdd(p.list_count, __popcll(mm));
+        at = __shfl(at, 0) + __popcll(mm & ((1ull << lane) - 1ull));
+        if (more) p.list[at] = b;
+    }
+    if (active && al == 0 && !more) {
+        p.alpha_idx[o] = found ? best : -1;
         p.Jtry[o] = best_cost;
-        p.slow_trig[o] = wave_bad ? 1 : 0;
+        p.slow_trig[o] = pbad ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------- evaluate, stage two
+// Few problems reach stage two (a few per cent of the batch, from anywhere in it), so few waves
+// run, each a serial chain over the horizon: the kernel is bound by latency, not by bandwidth.
+// One wave of L lanes per problem x 64/L problems therefore stages the rows of SB time steps at a
+// time through LDS: all lanes of a problem share the loads of a block (each value is fetched once
+// and every load of the block is in flight together), the block after it is fetched into
+// registers while the current one is rolled out, and the rollout reads its rows from LDS.
+template <class M, bool BARRIER, int L> struct ListedCfg {
+    static constexpr int NX = M::NX, NU = M::NU, PPW = 64 / L;
+    static constexpr int ROW = NU * NX + 2 * NU + 2 * NX + (BARRIER ? 3 : 0); // values per time step
+    static constexpr int FIT = 2560 / (PPW * ROW);                              // about 20 KB of fp64 per wave
+    static constexpr int SB = FIT >= 16 ? 16 : FIT >= 8 ? 8 : FIT >= 4 ? 4 : 2;
+    // per-problem LDS image of a block: K, k, U, X, Xref, centers, radius
+    static constexpr int nK = SB * NU * NX, nk = SB * NU, nX = SB * NX, nC = BARRIER ? SB * 2 : 0, nD = BARRIER ? SB : 0;
+    static constexpr int oK = 0, ok = oK + nK, oU = ok + nk, oX = oU + nk, oR = oX + nX, oC = oR + nX, oD = oC + nC;
+    static constexpr int TOTAL = oD + nD;
+    static constexpr int STRIDE = TOTAL | 1; // odd: the problems of a wave read from different banks
+    static constexpr int LDS = PPW * STRIDE;
+    static constexpr int cnt(int n) { return (n + L - 1) / L; } // values each lane fetches of an array of n
+};
+
+template <typename T, class M, bool BARRIER, int L> struct ListedStage { // one block in registers
+    using C = ListedCfg<M, BARRIER, L>;
+    T K[C::cnt(C::nK)], k[C::cnt(C::nk)], U[C::cnt(C::nk)], X[C::cnt(C::nX)], R[C::cnt(C::nX)];
+    T Cc[BARRIER ? C::cnt(C::nC) : 1], D[BARRIER ? C::cnt(C::nD) : 1];
+};
+
+template <typename T, class M, bool DIAG, bool BARRIER, int L, bool FAST, class P>
+__device__ __forceinline__ void listed_rounds(const P &p, const T *Xt, const T *Rt, const T *Ut, const T *Kp, const T *kp,
+                                              const T *Cp, const T *Dp, T *lds, int al, bool active, T Jcur, int base0, int end,
+                                              int &best, T &best_cost, bool &bad) {
+    using C = ListedCfg<M, BARRIER, L>;
+    constexpr int NX = M::NX, NU = M::NU, SB = C::SB;
+    const int T1 = p.N - 1;
+    // rows [r0, r0 + n) of an array with `rows` rows per problem: lane al takes every L-th; past
+    // either end the nearest valid row is fetched instead (no branch around a load)
+    auto fetch = [&](const T *src, int r0, int n, int rows, auto &dst) {
+#pragma unroll
+        for (int i = 0; i < C::cnt(n); ++i) {
+            int e = al + L * i;
+            e = e < n ? e : n - 1;
+            int r = r0 + e;
+            r = r < rows ? r : rows - 1;
+            dst[i] = src[(size_t)r * TILE];
+        }
+    };
+    auto put = [&](int off, int n, const auto &src) {
+#pragma unroll
+        for (int i = 0; i < C::cnt(n); ++i) {
+            int e = al + L * i;
+            e = e < n ? e : n - 1;
+            lds[off + e] = src[i];
+        }
+    };
+    auto fetch_block = [&](int t0, ListedStage<T, M, BARRIER, L> &st) {
+        fetch(Kp, t0 * NU * NX, C::nK, T1 * NU * NX, st.K);
+        fetch(kp, t0 * NU, C::nk, T1 * NU, st.k);
+        fetch(Ut, t0 * NU, C::nk, T1 * NU, st.U);
+        fetch(Xt, t0 * NX, C::nX, p.N * NX, st.X);
+        fetch(Rt, t0 * NX, C::nX, p.N * NX, st.R);
+        if (BARRIER) {
+            fetch(Cp, t0 * 2, C::nC, p.N * 2, st.Cc);
+            fetch(Dp, t0, C::nD, p.N, st.D);
+        }
+    };
+    best = 0x7fffffff;
+    best_cost = T(0);
+    for (int base = base0; base < end; base += L) {
+        const int a = base + al;
+        const T alpha = pow2_neg<T>(a);
+        T x[NX], cost = T(0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = Xt[i * TILE];
+        ListedStage<T, M, BARRIER, L> st;
+        fetch_block(0, st);
+        for (int t0 = 0; t0 < T1; t0 += SB) {
+            __syncthreads(); // the rollout of the previous block has read its rows
+            put(C::oK, C::nK, st.K);
+            put(C::ok, C::nk, st.k);
+            put(C::oU, C::nk, st.U);
+            put(C::oX, C::nX, st.X);
+            put(C::oR, C::nX, st.R);
+            if (BARRIER) {
+                put(C::oC, C::nC, st.Cc);
+                put(C::oD, C::nD, st.D);
+            }
+            __syncthreads();
+            fetch_block(t0 + SB, st); // in flight during the rollout below
+            const int ns = T1 - t0 < SB ? T1 - t0 : SB;
+            for (int s = 0; s < ns; ++s) {
+                FwdRow<T, NX, NU> r;
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    r.k[i] = lds[C::ok + s * NU + i];
+                    r.up[i] = lds[C::oU + s * NU + i];
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) r.K[i][j] = lds[C::oK + (s * NU + i) * NX + j];
+                }
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    r.xp[i] = lds[C::oX + s * NX + i];
+                    r.xr[i] = lds[C::oR + s * NX + i];
+                }
+                if (BARRIER) {
+                    r.cx = lds[C::oC + s * 2 + 0];
+                    r.cy = lds[C::oC + s * 2 + 1];
+                    r.rad = lds[C::oD + s];
+                } else {
+                    r.cx = r.cy = r.rad = T(0);
+                }
+                candidate_step<T, M, DIAG, BARRIER, FAST>(p, t0 + s, alpha, r, x, cost, bad);
+            }
+        }
+        T xr[NX], cx = T(0), cy = T(0), rad = T(0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xr[i] = Rt[(T1 * NX + i) * TILE];
+        if (BARRIER) {
+            cx = Cp[(T1 * 2 + 0) * TILE];
+            cy = Cp[(T1 * 2 + 1) * TILE];
+            rad = Dp[T1 * TILE];
+        }
+        const T c = candidate_total<T, M, DIAG, BARRIER>(p, x, xr, cx, cy, rad, cost);
+        int cand = 0x7fffffff;
+        T cand_cost = T(0);
+        if (a < end && c < Jcur) { // strict test of ilqr.py:65; NaN never passes
+            cand = a;
+            cand_cost = c;
+        }
+#pragma unroll
+        for (int off = 1; off < L; off <<= 1) { // lowest candidate index among the L lanes of the problem
+            int oc = __shfl_xor(cand, off);
+            T ocost = __shfl_xor(cand_cost, off);
+            if (oc < cand) {
+                cand = oc;
+                cand_cost = ocost;
+            }
+        }
+        if (best == 0x7fffffff && cand != 0x7fffffff) {
+            best = cand;
+            best_cost = cand_cost;
+        }
+        if (__ballot(active && best == 0x7fffffff) == 0ull) break;
+    }
+}
+
+// one wave per workgroup; the grid covers the worst case (every problem listed) and the waves
+// beyond the end of the list leave at once
+template <typename T, class M, bool DIAG, bool BARRIER, int L>
+__global__ __launch_bounds__(64) void evaluate_listed_kernel(Params<T, M::NX, M::NU> p, int base0, int end) {
+    using C = ListedCfg<M, BARRIER, L>;
+    constexpr int NX = M::NX, NU = M::NU, PPW = C::PPW;
+    __shared__ T rows[C::LDS];
+    const int lane = threadIdx.x;
+    const int pl = lane / L, al = lane % L;
+    const int nsl = *p.list_count;
+    if ((int)blockIdx.x * PPW >= nsl) return;
+    const int g = blockIdx.x * PPW + pl;
+    const bool valid = g < nsl;
+    const int b = p.list[valid ? g : nsl - 1]; // slot
+    const int o = orig_of(p, b);
+    const bool active = valid; // listed problems are active by construction
+    const int T1 = p.N - 1;
+    const T Jcur = p.J[o];
+    const int tile = b >> 6, ln = b & 63;
+    const T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
+    const T *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
+    const T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
+    const T *Cp = BARRIER ? tile_ptr(p.centers, tile, p.N * 2, ln) : nullptr;
+    const T *Dp = BARRIER ? tile_ptr(p.radius, tile, p.N, ln) : nullptr;
+    const T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
+    const T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    T *lds = rows + pl * C::STRIDE;
+    int best;
+    T best_cost;
+    bool bad = false;
+    listed_rounds<T, M, DIAG, BARRIER, L, true>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, lds, al, active, Jcur, base0, end, best, best_cost, bad);
+    bool pbad = bad; // as in evaluate_kernel
+#pragma unroll
+    for (int w = 1; w < L; w <<= 1) pbad |= __shfl_xor((int)pbad, w) != 0;
+    if (__ballot(pbad && active) != 0ull) {
+        int best2;
+        T best_cost2;
+        bool bad2 = false;
+        listed_rounds<T, M, DIAG, BARRIER, L, false>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, lds, al, active, Jcur, base0, end, best2, best_cost2, bad2);
+        best = pbad ? best2 : best;
+        best_cost = pbad ? best_cost2 : best_cost;
+    }
+    if (active && al == 0) {
+        const bool found = best != 0x7fffffff;
+        p.alpha_idx[o] = found ? best : -1;
+        p.Jtry[o] = best_cost;
+        p.slow_trig[o] = pbad ? 1 : 0;
     }
 }
 
