@@ -41,7 +41,7 @@ class DeviceProblem:
     def __init__(self, system, B, N, dtype, device, *, max_iter, lm_parameter, alpha_floor,
                  constraint_mode=_lib.CONSTR_NONE, input_limit_lambda=1e-4, barrier_mu=0.0,
                  barrier_delta=0.1, vel_bounds=(0.0, 0.0), lanes_per_problem=0, alphas_per_lane=0,
-                 history=False, solver_limits=False, n_streams=0, repack_every=0):
+                 history=False, solver_limits=False, n_streams=0, repack_every=0, recompute_states=0):
         torch = _torch()
         if not torch.cuda.is_available():
             raise _lib.IlqrError("no GPU visible: the batched iLQR solve runs on the HIP device only")
@@ -67,6 +67,7 @@ class DeviceProblem:
         d.lanes_per_problem, d.alphas_per_lane = int(lanes_per_problem), int(alphas_per_lane)
         d.n_streams = int(n_streams)
         d.repack_every = int(repack_every)
+        d.recompute_states = int(recompute_states)
         d.dt = float(system.dt)
         d.lm_parameter = float(lm_parameter)
         d.alpha_floor = float(alpha_floor)
@@ -243,7 +244,7 @@ class BatchedSolverBase:
     _constraint_mode = _lib.CONSTR_NONE
 
     def __init__(self, sys, target_states, dt, device=None, dtype=np.float64, history=False,
-                 lanes_per_problem=0, alphas_per_lane=0, n_streams=0, repack_every=0):
+                 lanes_per_problem=0, alphas_per_lane=0, n_streams=0, repack_every=0, recompute_states=0):
         if not isinstance(sys, System) and not hasattr(sys, "state_size"):
             raise TypeError("sys must provide the systems.System interface")
         self.target_states = target_states
@@ -281,6 +282,7 @@ class BatchedSolverBase:
         self._mapping = (int(lanes_per_problem), int(alphas_per_lane))
         self._n_streams = int(n_streams)
         self._repack_every = int(repack_every)
+        self._recompute_states = int(recompute_states)
         self._dev = None
         self._k_cache = self._K_cache = None
         self.cost_history = None
@@ -315,7 +317,8 @@ class BatchedSolverBase:
                 lm_parameter=self.LM_parameter, alpha_floor=self._alpha_floor(),
                 constraint_mode=self._constraint_mode, history=self._history,
                 lanes_per_problem=self._mapping[0], alphas_per_lane=self._mapping[1],
-                n_streams=self._n_streams, repack_every=self._repack_every, **self._extra_desc())
+                n_streams=self._n_streams, repack_every=self._repack_every,
+                recompute_states=self._recompute_states, **self._extra_desc())
             self._dev_key = key
         return self._dev
 

@@ -191,19 +191,27 @@ int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
     if (na <= 0 || na > 64) return ILQR_ERR_INVALID;
     int L = d.lanes_per_problem, A = d.alphas_per_lane;
     if (L == 0 && A == 0) {
-        // All 16 candidates of a round are rolled out at once; how they are spread over lanes is a
-        // pure speed choice.  Few lanes per problem means more independent rollouts per lane
-        // (instruction-level parallelism, shared row loads); many lanes per problem means more
-        // waves, which small batches need to occupy the 1024 SIMDs.  Aim at >= 2048 waves.
-        L = d.n > 8 ? 8 : 2;
-        while (L < 16 && (long)d.B * L < 131072L) L *= 2;
-        A = 16 / L;
+        // How the candidates of a round are spread over lanes is a pure speed choice.  Few lanes
+        // per problem means more independent rollouts per lane (instruction-level parallelism,
+        // shared row loads); many lanes per problem means more waves, which small batches need to
+        // occupy the 1024 SIMDs.  Eight candidates per round settle all but a few per cent of the
+        // problems; the rest finish in the second stage (evaluate_listed_kernel).  The large model
+        // is only built with 16 candidates per round.
+        if (d.n > 8) {
+            L = 8;
+            while (L < 16 && (long)d.B * L < 131072L) L *= 2;
+            A = 16 / L;
+        } else {
+            L = 1;
+            while (L < 8 && (long)d.B * L < 65536L) L *= 2;
+            A = 8 / L;
+        }
     } else if (L == 0 || A == 0) {
         return ILQR_ERR_INVALID;
     }
     {
         const int key = L * 100 + A;
-        const int ok[] = {1601, 802, 404, 208, 116, 801, 402, 204, 108, 401, 104};
+        const int ok[] = {1601, 802, 404, 208, 801, 402, 204, 108};
         bool found = false;
         for (int v : ok) found = found || (v == key);
         if (!found) return ILQR_ERR_UNSUPPORTED;
@@ -263,6 +271,7 @@ int ilqr_bind(ilqr_handle *h, const ilqr_buffers *b) {
     if ((b->hist_cost || b->hist_alpha) && b->hist_capacity <= 0) return ILQR_ERR_INVALID;
     h->ctx.b = *b;
     h->ctx.bound = true;
+    h->ctx.reroll = false;
     return ILQR_OK;
 }
 
@@ -272,6 +281,7 @@ int ilqr_bind(ilqr_handle *h, const ilqr_buffers *b) {
 
 int ilqr_initial_cost(ilqr_handle *h, void *stream) {
     REQUIRE_BOUND(h);
+    h->ctx.reroll = false; // the caller (re)wrote X and U: X need not be the rollout of U
     return hip_rc(h->ops->cost(h->ctx, 0, (hipStream_t)stream));
 }
 
@@ -288,7 +298,10 @@ int ilqr_forward_evaluate(ilqr_handle *h, void *stream) {
 int ilqr_forward_commit(ilqr_handle *h, int32_t iteration, void *stream) {
     REQUIRE_BOUND(h);
     if (iteration < 0) return ILQR_ERR_INVALID;
-    return hip_rc(h->ops->commit(h->ctx, iteration, (hipStream_t)stream));
+    const int rc = hip_rc(h->ops->commit(h->ctx, iteration, (hipStream_t)stream));
+    // every problem that is still active afterwards has had a step committed by this library
+    if (rc == ILQR_OK && h->ctx.d.recompute_states >= 0) h->ctx.reroll = true;
+    return rc;
 }
 
 int ilqr_forward(ilqr_handle *h, int32_t iteration, void *stream) {
@@ -323,6 +336,7 @@ int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream) {
     int rc = ILQR_OK;
     PartState part[MAX_PARTS];
     hipStream_t st[MAX_PARTS];
+    h->ctx.reroll = false; // ilqr_solve starts from the caller's trajectory
     for (int s = 0; s < np; ++s) {
         part[s].ctx = h->ctx;
         part[s].index = s;
@@ -344,6 +358,8 @@ int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream) {
     int prev = -1;
     for (int it = 0; it < max_iter && rc == ILQR_OK; ++it)
         for (int s = 0; s < np && rc == ILQR_OK; ++s) {
+            // from the second iteration on, every active problem's X is this library's rollout of U
+            part[s].ctx.reroll = it > 0 && h->ctx.d.recompute_states >= 0;
             if (h->repack_every > 0 && it > 0 && it % h->repack_every == 0) rc = repack(h, part[s], false, st[s]);
             if (rc == ILQR_OK) rc = hip_rc(h->ops->backward(part[s].ctx, 0, st[s]));
             if (np > 1) {

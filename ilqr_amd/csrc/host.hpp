@@ -18,6 +18,10 @@ struct HostCtx {
     // a launch may cover only the problems [first, first + count) of the bound batch
     // (first is a multiple of 64 so that the part starts on a tile boundary)
     int first = 0, count = 0;
+    // the trajectory in X is the library's own rollout of U for every non-converged problem
+    // (true between a commit and the next change of the buffers): the forward kernels may then
+    // roll the previous states out again instead of reading them
+    bool reroll = false;
     // working set of ilqr_solve's active-set compaction: when `slot2orig` is set, the tiled
     // arrays below replace the bound ones (they are already relative to this part and hold
     // *nslots problems in slot order) and the per-problem arrays are indexed through the map
@@ -28,10 +32,10 @@ struct HostCtx {
     } ws;
 };
 
-// Layout of the caller-provided `work` buffer (byte offsets).  The first five regions always
+// Layout of the caller-provided `work` buffer (byte offsets).  The first six regions always
 // exist; the rest only with active-set compaction.
 struct WorkLayout {
-    size_t jtry = 0, slow = 0, counters = 0, list = 0, list_count = 0;
+    size_t jtry = 0, slow = 0, counters = 0, list = 0, list_count = 0, trash = 0;
     size_t map[2] = {0, 0}, tile_count = 0, tile_offset = 0, nslots = 0;
     size_t set[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}; // X, U, Xref, centers, radius of the two working sets
     size_t Kw = 0, kw = 0;
@@ -53,6 +57,7 @@ static inline WorkLayout work_layout(const ilqr_desc &d, bool compaction) {
     w.counters = take(256);
     w.list = take(Bp * 4);          // line-search stage two: slots still without a winner
     w.list_count = take(tiles * 4); // their number, one counter per possible first tile of a part
+    w.trash = take(Bp * e);         // one value per lane: sink of the stores of lanes that keep their trajectory
     if (compaction) {
         const size_t N = d.N, T1 = d.N - 1, n = d.n, m = d.m;
         const bool barrier = (d.constraint_mode & ILQR_CONSTR_BARRIER) != 0;
@@ -123,6 +128,7 @@ template <typename T, int NX, int NU> static Params<T, NX, NU> make_params(const
     p.nslots = c.ws.nslots;
     p.list = (int32_t *)((char *)b.work + wl.list) + c.first;
     p.list_count = (int32_t *)((char *)b.work + wl.list_count) + tile0;
+    p.trash = (T *)((char *)b.work + wl.trash) + c.first;
     p.J = flat((T *)b.J);
     p.Jtry = flat((T *)((char *)b.work + wl.jtry));
     p.slow_trig = flat((int32_t *)((char *)b.work + wl.slow));
@@ -214,6 +220,9 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
     // Line search in two stages: the L*A first candidates for every active problem, then the
     // rest for the few problems that found no winner among them (kernels.hpp, evaluate_kernel)
     template <bool BARRIER, int L, int A> static hipError_t eval_la(const HostCtx &c, hipStream_t s) {
+        return c.reroll ? eval_lar<BARRIER, L, A, true>(c, s) : eval_lar<BARRIER, L, A, false>(c, s);
+    }
+    template <bool BARRIER, int L, int A, bool REROLL> static hipError_t eval_lar(const HostCtx &c, hipStream_t s) {
         auto p = make_params<T, NX, NU>(c);
         const int first_end = c.n_alphas < L * A ? c.n_alphas : L * A;
         const bool two = first_end < c.n_alphas;
@@ -225,7 +234,7 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
             const int ppw = 64 / L;                    // problems per wave
             const long waves = ((long)c.count + ppw - 1) / ppw;
             const int blocks = (int)((waves + 3) / 4); // 4 waves per workgroup
-            hipLaunchKernelGGL((evaluate_kernel<T, M, DIAG, BARRIER, L, A>), dim3(blocks), dim3(256), 0, s, p, first_end);
+            hipLaunchKernelGGL((evaluate_kernel<T, M, DIAG, BARRIER, L, A, REROLL>), dim3(blocks), dim3(256), 0, s, p, first_end);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess || !two) return e;
         }
@@ -234,7 +243,7 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
         constexpr int L2 = M::NX > 8 ? 16 : 8;
         const int ppw = 64 / L2;
         const int blocks = (int)(((long)c.count + ppw - 1) / ppw); // one wave per workgroup
-        hipLaunchKernelGGL((evaluate_listed_kernel<T, M, DIAG, BARRIER, L2>), dim3(blocks), dim3(64), 0, s, p, first_end, c.n_alphas);
+        hipLaunchKernelGGL((evaluate_listed_kernel<T, M, DIAG, BARRIER, L2, REROLL>), dim3(blocks), dim3(64), 0, s, p, first_end, c.n_alphas);
         return hipGetLastError();
     }
     template <bool BARRIER> static hipError_t eval_b(const HostCtx &c, hipStream_t s) {
@@ -252,14 +261,11 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
             case 1601: return eval_la<BARRIER, 16, 1>(c, s);
             case 802: return eval_la<BARRIER, 8, 2>(c, s);
             case 404: return eval_la<BARRIER, 4, 4>(c, s);
-            case 116: return eval_la<BARRIER, 1, 16>(c, s);
             case 208: return eval_la<BARRIER, 2, 8>(c, s);
             case 801: return eval_la<BARRIER, 8, 1>(c, s);
             case 402: return eval_la<BARRIER, 4, 2>(c, s);
             case 204: return eval_la<BARRIER, 2, 4>(c, s);
             case 108: return eval_la<BARRIER, 1, 8>(c, s);
-            case 401: return eval_la<BARRIER, 4, 1>(c, s);
-            case 104: return eval_la<BARRIER, 1, 4>(c, s);
             default: return hipErrorInvalidValue;
             }
         }
@@ -271,10 +277,13 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
         if (barrier_on(c)) return hipErrorInvalidValue;
         return eval_b<false>(c, s);
     }
-    static hipError_t commit(const HostCtx &c, int it, hipStream_t s) {
+    template <bool REROLL> static hipError_t commit_r(const HostCtx &c, int it, hipStream_t s) {
         auto p = make_params<T, NX, NU>(c);
-        hipLaunchKernelGGL((commit_kernel<T, M, PF_COMMIT>), dim3((c.count + 63) / 64), dim3(64), 0, s, p, it);
+        hipLaunchKernelGGL((commit_kernel<T, M, PF_COMMIT, REROLL>), dim3((c.count + 63) / 64), dim3(64), 0, s, p, it);
         return hipGetLastError();
+    }
+    static hipError_t commit(const HostCtx &c, int it, hipStream_t s) {
+        return c.reroll ? commit_r<true>(c, it, s) : commit_r<false>(c, it, s);
     }
     static const ModelOps *table() {
         static const ModelOps ops = {&cost, &backward, &evaluate, &commit};

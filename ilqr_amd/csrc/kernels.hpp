@@ -113,7 +113,7 @@ template <typename T, int NX, int NU> struct Params {
     T *K, *k;
     T *J, *Jtry;
     int32_t *converged, *iters, *alpha_idx, *status;
-    int32_t *slow_trig; // per problem: the evaluate kernel needed the library sine/cosine
+    int32_t *slow_trig; // per problem: which sine/cosine its line search and commits used (bits: see commit_kernel)
     // Active-set compaction (ilqr_solve only): the tiled trajectory arrays then hold `*nslots`
     // problems in slot order and slot2orig[slot] is the problem's index in the per-problem arrays
     // (J, converged, iters, alpha_idx, status, Jtry, slow_trig, history).  Both null otherwise.
@@ -123,6 +123,7 @@ template <typename T, int NX, int NU> struct Params {
     // before stage one, the stage-one kernel appends)
     int32_t *list;
     int32_t *list_count;
+    T *trash; // 64 values per tile: where lanes that must not change their trajectory store (commit, REROLL)
     const T *centers, *radius;
     const T *ltvA, *ltvB;
     T *hist_cost;
@@ -853,7 +854,11 @@ __device__ __forceinline__ T candidate_total(const P &p, const T (&x)[M::NX], co
 // rounds continue (in increasing index order, so the largest improving step
 // wins exactly as in the serial search) until every problem of the wave has a
 // winner or the candidates are exhausted.
-template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool FAST, class P>
+// REROLL: the trajectory in X is the rollout of the inputs in U by this very code (true once a
+// line search has committed a step, see commit_kernel), so the previous states the feedback
+// term needs are rolled out again in registers instead of being read: one more model step per
+// time step, NX fewer values of traffic.
+template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool REROLL, bool FAST, class P>
 __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T *Rt, const T *Ut, const T *Kp, const T *kp,
                                                 const T *Cp, const T *Dp, int al, bool active, T Jcur, int base0, int end,
                                                 int &best, T &best_cost, bool &bad) {
@@ -869,7 +874,7 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            r.xp[i] = Xt[(t * NX + i) * TILE];
+            if (!REROLL) r.xp[i] = Xt[(t * NX + i) * TILE];
             r.xr[i] = Rt[(t * NX + i) * TILE];
         }
         if (BARRIER) {
@@ -891,13 +896,26 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
 #pragma unroll
             for (int i = 0; i < NX; ++i) x[j][i] = Xt[i * TILE];
         }
+        T xq[NX]; // state of the previous trajectory (REROLL)
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xq[i] = Xt[i * TILE];
         FwdRow<T, NX, NU> nxt;
         load_row(0, nxt);
         for (int t = 0; t < T1; ++t) {
             FwdRow<T, NX, NU> r = nxt;
             if (t + 1 < T1) load_row(t + 1, nxt);
+            if (REROLL) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) r.xp[i] = xq[i];
+            }
 #pragma unroll
             for (int j = 0; j < A; ++j) candidate_step<T, M, DIAG, BARRIER, FAST>(p, t, alpha[j], r, x[j], cost[j], bad);
+            if (REROLL) {
+                T xqn[NX];
+                M::template step<FAST>(p, t, xq, r.up, xqn, bad);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xq[i] = xqn[i];
+            }
         }
         // terminal term (ilqr.py:44-45)
         T xr[NX], cx = T(0), cy = T(0), rad = T(0);
@@ -943,7 +961,7 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
 // them while candidates remain is appended to a device-side list; stage two
 // (evaluate_listed_kernel) walks that list with the remaining candidates.  Candidates are still
 // examined in increasing index order, so the result is that of the serial search.
-template <typename T, class M, bool DIAG, bool BARRIER, int L, int A>
+template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool REROLL>
 __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T, M::NX, M::NU> p, int end) {
     constexpr int NX = M::NX, NU = M::NU;
     constexpr int PPW = 64 / L; // problems per wave
@@ -971,7 +989,7 @@ __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T,
     int best;
     T best_cost;
     bool bad = false;
-    evaluate_rounds<T, M, DIAG, BARRIER, L, A, true>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, 0, end, best, best_cost, bad);
+    evaluate_rounds<T, M, DIAG, BARRIER, L, A, REROLL, true>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, 0, end, best, best_cost, bad);
     // an angle outside the fast trigonometric range anywhere in the wave: redo with the library
     // routine; a problem one of whose lanes saw such an angle takes the redone result (and tells
     // the commit kernel to use the library routine too), the others keep theirs, so a problem's
@@ -983,7 +1001,7 @@ __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T,
         int best2;
         T best_cost2;
         bool bad2 = false;
-        evaluate_rounds<T, M, DIAG, BARRIER, L, A, false>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, 0, end, best2, best_cost2, bad2);
+        evaluate_rounds<T, M, DIAG, BARRIER, L, A, REROLL, false>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, 0, end, best2, best_cost2, bad2);
         best = pbad ? best2 : best;
         best_cost = pbad ? best_cost2 : best_cost;
     }
@@ -1000,7 +1018,7 @@ __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T,
     if (active && al == 0 && !more) {
         p.alpha_idx[o] = found ? best : -1;
         p.Jtry[o] = best_cost;
-        p.slow_trig[o] = pbad ? 1 : 0;
+        p.slow_trig[o] = (p.slow_trig[o] & 6) | (pbad ? 1 : 0);
     }
 }
 
@@ -1011,31 +1029,31 @@ __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T,
 // time through LDS: all lanes of a problem share the loads of a block (each value is fetched once
 // and every load of the block is in flight together), the block after it is fetched into
 // registers while the current one is rolled out, and the rollout reads its rows from LDS.
-template <class M, bool BARRIER, int L> struct ListedCfg {
+template <class M, bool BARRIER, int L, bool REROLL> struct ListedCfg {
     static constexpr int NX = M::NX, NU = M::NU, PPW = 64 / L;
-    static constexpr int ROW = NU * NX + 2 * NU + 2 * NX + (BARRIER ? 3 : 0); // values per time step
+    static constexpr int ROW = NU * NX + 2 * NU + (REROLL ? 1 : 2) * NX + (BARRIER ? 3 : 0); // values per time step
     static constexpr int FIT = 2560 / (PPW * ROW);                              // about 20 KB of fp64 per wave
     static constexpr int SB = FIT >= 16 ? 16 : FIT >= 8 ? 8 : FIT >= 4 ? 4 : 2;
     // per-problem LDS image of a block: K, k, U, X, Xref, centers, radius
     static constexpr int nK = SB * NU * NX, nk = SB * NU, nX = SB * NX, nC = BARRIER ? SB * 2 : 0, nD = BARRIER ? SB : 0;
-    static constexpr int oK = 0, ok = oK + nK, oU = ok + nk, oX = oU + nk, oR = oX + nX, oC = oR + nX, oD = oC + nC;
+    static constexpr int oK = 0, ok = oK + nK, oU = ok + nk, oX = oU + nk, oR = oX + (REROLL ? 0 : nX), oC = oR + nX, oD = oC + nC;
     static constexpr int TOTAL = oD + nD;
     static constexpr int STRIDE = TOTAL | 1; // odd: the problems of a wave read from different banks
     static constexpr int LDS = PPW * STRIDE;
     static constexpr int cnt(int n) { return (n + L - 1) / L; } // values each lane fetches of an array of n
 };
 
-template <typename T, class M, bool BARRIER, int L> struct ListedStage { // one block in registers
-    using C = ListedCfg<M, BARRIER, L>;
-    T K[C::cnt(C::nK)], k[C::cnt(C::nk)], U[C::cnt(C::nk)], X[C::cnt(C::nX)], R[C::cnt(C::nX)];
+template <typename T, class M, bool BARRIER, int L, bool REROLL> struct ListedStage { // one block in registers
+    using C = ListedCfg<M, BARRIER, L, REROLL>;
+    T K[C::cnt(C::nK)], k[C::cnt(C::nk)], U[C::cnt(C::nk)], X[REROLL ? 1 : C::cnt(C::nX)], R[C::cnt(C::nX)];
     T Cc[BARRIER ? C::cnt(C::nC) : 1], D[BARRIER ? C::cnt(C::nD) : 1];
 };
 
-template <typename T, class M, bool DIAG, bool BARRIER, int L, bool FAST, class P>
+template <typename T, class M, bool DIAG, bool BARRIER, int L, bool REROLL, bool FAST, class P>
 __device__ __forceinline__ void listed_rounds(const P &p, const T *Xt, const T *Rt, const T *Ut, const T *Kp, const T *kp,
                                               const T *Cp, const T *Dp, T *lds, int al, bool active, T Jcur, int base0, int end,
                                               int &best, T &best_cost, bool &bad) {
-    using C = ListedCfg<M, BARRIER, L>;
+    using C = ListedCfg<M, BARRIER, L, REROLL>;
     constexpr int NX = M::NX, NU = M::NU, SB = C::SB;
     const int T1 = p.N - 1;
     // rows [r0, r0 + n) of an array with `rows` rows per problem: lane al takes every L-th; past
@@ -1058,11 +1076,11 @@ __device__ __forceinline__ void listed_rounds(const P &p, const T *Xt, const T *
             lds[off + e] = src[i];
         }
     };
-    auto fetch_block = [&](int t0, ListedStage<T, M, BARRIER, L> &st) {
+    auto fetch_block = [&](int t0, ListedStage<T, M, BARRIER, L, REROLL> &st) {
         fetch(Kp, t0 * NU * NX, C::nK, T1 * NU * NX, st.K);
         fetch(kp, t0 * NU, C::nk, T1 * NU, st.k);
         fetch(Ut, t0 * NU, C::nk, T1 * NU, st.U);
-        fetch(Xt, t0 * NX, C::nX, p.N * NX, st.X);
+        if (!REROLL) fetch(Xt, t0 * NX, C::nX, p.N * NX, st.X);
         fetch(Rt, t0 * NX, C::nX, p.N * NX, st.R);
         if (BARRIER) {
             fetch(Cp, t0 * 2, C::nC, p.N * 2, st.Cc);
@@ -1077,14 +1095,17 @@ __device__ __forceinline__ void listed_rounds(const P &p, const T *Xt, const T *
         T x[NX], cost = T(0);
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = Xt[i * TILE];
-        ListedStage<T, M, BARRIER, L> st;
+        T xq[NX]; // state of the previous trajectory (REROLL)
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xq[i] = x[i];
+        ListedStage<T, M, BARRIER, L, REROLL> st;
         fetch_block(0, st);
         for (int t0 = 0; t0 < T1; t0 += SB) {
             __syncthreads(); // the rollout of the previous block has read its rows
             put(C::oK, C::nK, st.K);
             put(C::ok, C::nk, st.k);
             put(C::oU, C::nk, st.U);
-            put(C::oX, C::nX, st.X);
+            if (!REROLL) put(C::oX, C::nX, st.X);
             put(C::oR, C::nX, st.R);
             if (BARRIER) {
                 put(C::oC, C::nC, st.Cc);
@@ -1104,7 +1125,7 @@ __device__ __forceinline__ void listed_rounds(const P &p, const T *Xt, const T *
                 }
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
-                    r.xp[i] = lds[C::oX + s * NX + i];
+                    r.xp[i] = REROLL ? xq[i] : lds[C::oX + s * NX + i];
                     r.xr[i] = lds[C::oR + s * NX + i];
                 }
                 if (BARRIER) {
@@ -1115,6 +1136,12 @@ __device__ __forceinline__ void listed_rounds(const P &p, const T *Xt, const T *
                     r.cx = r.cy = r.rad = T(0);
                 }
                 candidate_step<T, M, DIAG, BARRIER, FAST>(p, t0 + s, alpha, r, x, cost, bad);
+                if (REROLL) {
+                    T xqn[NX];
+                    M::template step<FAST>(p, t0 + s, xq, r.up, xqn, bad);
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) xq[i] = xqn[i];
+                }
             }
         }
         T xr[NX], cx = T(0), cy = T(0), rad = T(0);
@@ -1151,9 +1178,9 @@ __device__ __forceinline__ void listed_rounds(const P &p, const T *Xt, const T *
 
 // one wave per workgroup; the grid covers the worst case (every problem listed) and the waves
 // beyond the end of the list leave at once
-template <typename T, class M, bool DIAG, bool BARRIER, int L>
+template <typename T, class M, bool DIAG, bool BARRIER, int L, bool REROLL>
 __global__ __launch_bounds__(64) void evaluate_listed_kernel(Params<T, M::NX, M::NU> p, int base0, int end) {
-    using C = ListedCfg<M, BARRIER, L>;
+    using C = ListedCfg<M, BARRIER, L, REROLL>;
     constexpr int NX = M::NX, NU = M::NU, PPW = C::PPW;
     __shared__ T rows[C::LDS];
     const int lane = threadIdx.x;
@@ -1179,7 +1206,7 @@ __global__ __launch_bounds__(64) void evaluate_listed_kernel(Params<T, M::NX, M:
     int best;
     T best_cost;
     bool bad = false;
-    listed_rounds<T, M, DIAG, BARRIER, L, true>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, lds, al, active, Jcur, base0, end, best, best_cost, bad);
+    listed_rounds<T, M, DIAG, BARRIER, L, REROLL, true>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, lds, al, active, Jcur, base0, end, best, best_cost, bad);
     bool pbad = bad; // as in evaluate_kernel
 #pragma unroll
     for (int w = 1; w < L; w <<= 1) pbad |= __shfl_xor((int)pbad, w) != 0;
@@ -1187,7 +1214,7 @@ __global__ __launch_bounds__(64) void evaluate_listed_kernel(Params<T, M::NX, M:
         int best2;
         T best_cost2;
         bool bad2 = false;
-        listed_rounds<T, M, DIAG, BARRIER, L, false>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, lds, al, active, Jcur, base0, end, best2, best_cost2, bad2);
+        listed_rounds<T, M, DIAG, BARRIER, L, REROLL, false>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, lds, al, active, Jcur, base0, end, best2, best_cost2, bad2);
         best = pbad ? best2 : best;
         best_cost = pbad ? best_cost2 : best_cost;
     }
@@ -1195,7 +1222,7 @@ __global__ __launch_bounds__(64) void evaluate_listed_kernel(Params<T, M::NX, M:
         const bool found = best != 0x7fffffff;
         p.alpha_idx[o] = found ? best : -1;
         p.Jtry[o] = best_cost;
-        p.slow_trig[o] = pbad ? 1 : 0;
+        p.slow_trig[o] = (p.slow_trig[o] & 6) | (pbad ? 1 : 0);
     }
 }
 
@@ -1204,8 +1231,15 @@ __global__ __launch_bounds__(64) void evaluate_listed_kernel(Params<T, M::NX, M:
 // overwrites X and U in place (each lane reads a row before it overwrites it);
 // problems without an accepted step keep their trajectory and become converged
 // (ilqr.py:69-73).
-template <typename T, class M, int PF, bool FAST, class P>
-__device__ __forceinline__ void commit_sweep(const P &p, T *Xt, T *Ut, const T *Kp, const T *kp, T alpha, bool roll) {
+// REROLL (see evaluate_rounds): the previous states are rolled out again from the stored inputs
+// instead of being read.  A lane that must leave its trajectory unchanged (converged problem,
+// no accepted step, padding) then has no old state values to write back.  If its stored states
+// are known to be this code's rollout of its inputs (`keep_ok`), the recomputed states are the
+// stored bits and are written back, which keeps every store a full line; otherwise its state
+// stores go to a scratch slot `trash` (still no branch around the stores).
+template <typename T, class M, int PF, bool REROLL, bool FAST, class P>
+__device__ __forceinline__ void commit_sweep(const P &p, T *Xt, T *Ut, const T *Kp, const T *kp, T *trash, T alpha, bool roll,
+                                             bool keep_ok) {
     constexpr int NX = M::NX, NU = M::NU;
     const int T1 = p.N - 1;
     struct Row {
@@ -1219,37 +1253,61 @@ __device__ __forceinline__ void commit_sweep(const P &p, T *Xt, T *Ut, const T *
 #pragma unroll
             for (int j = 0; j < NX; ++j) r.K[i][j] = Kp[((t * NU + i) * NX + j) * TILE];
         }
+        if (!REROLL) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) r.xp[i] = Xt[(t * NX + i) * TILE];
+            for (int i = 0; i < NX; ++i) r.xp[i] = Xt[(t * NX + i) * TILE];
+        }
     };
-    T x[NX];
+    T x[NX], xq[NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) x[i] = Xt[i * TILE];
+    for (int i = 0; i < NX; ++i) xq[i] = x[i] = Xt[i * TILE];
     Row nxt;
     load_row(0, nxt);
     T xlast[NX]; // previous states of the terminal step, needed to keep lanes without a winner unchanged
+    if (!REROLL) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) xlast[i] = Xt[(T1 * NX + i) * TILE];
-    bool bad = false;
+        for (int i = 0; i < NX; ++i) xlast[i] = Xt[(T1 * NX + i) * TILE];
+    }
+    bool bad = false, badq = false;
     for (int t = 0; t < T1; ++t) {
         Row r = nxt;
         // the row of step t+1 is read here, before the store to it below
         if (t + 1 < T1) load_row(t + 1, nxt);
+        if (REROLL) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) r.xp[i] = xq[i];
+        }
         T un[NU], xn[NX];
         control_update<T, M>(p, alpha, x, r.xp, r.up, r.K, r.k, un);
         M::template step<FAST>(p, t, x, un, xn, bad);
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = xn[i];
+        if (REROLL) {
+            T xqn[NX];
+            M::template step<FAST>(p, t, xq, r.up, xqn, badq);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xq[i] = xqn[i];
+        }
         // Every lane stores; a lane whose problem has no accepted step writes back the values it
         // read (no branch around the stores: see backward_sweep)
 #pragma unroll
         for (int i = 0; i < NU; ++i) Ut[(t * NU + i) * TILE] = roll ? un[i] : r.up[i];
+        // the recomputed old states are the stored ones only while the fast trigonometry was in
+        // range (the library routine may differ from it in the last bit)
+        const bool real = roll || (FAST && keep_ok && !badq);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) Xt[((t + 1) * NX + i) * TILE] = roll ? xn[i] : (t + 1 < T1 ? nxt.xp[i] : xlast[i]);
+        for (int i = 0; i < NX; ++i) {
+            if (REROLL) {
+                T *dst = real ? &Xt[((t + 1) * NX + i) * TILE] : trash;
+                *dst = roll ? xn[i] : xq[i];
+            } else {
+                Xt[((t + 1) * NX + i) * TILE] = roll ? xn[i] : (t + 1 < T1 ? nxt.xp[i] : xlast[i]);
+            }
+        }
     }
 }
 
-template <typename T, class M, int PF>
+template <typename T, class M, int PF, bool REROLL>
 __global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, int it) {
     constexpr int NX = M::NX, NU = M::NU;
     const int b0 = blockIdx.x * 64 + threadIdx.x;
@@ -1265,9 +1323,26 @@ __global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, i
     T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
     const T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
     const T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    T *trash = REROLL ? p.trash + b0 : nullptr;
     const int idx = p.alpha_idx[b];
     const bool roll = active && idx >= 0;
-    const bool slow = roll && p.slow_trig[b] != 0;
+    // slow_trig bits: 1 = this line search needed the library sine/cosine (set by the evaluate
+    // kernels); 2 = some step of this problem was committed by the library-routine sweep;
+    // 4 = a step of this problem has been committed since the caller last wrote its trajectory.
+    // The first commit after that (always the variant that reads X) defines bits 2 and 4 for
+    // every problem, so nothing depends on what the workspace held before.
+    const int slow_bits = p.slow_trig[b];
+    const bool slow = roll && (slow_bits & 1) != 0;
+    const bool wave_slow = __ballot(slow) != 0ull;
+    // stored states = this code's fast-path rollout of the stored inputs
+    const bool keep_ok = !valid || (slow_bits & 6) == 4;
+    if (valid) {
+        const int committed = roll ? (4 | (wave_slow ? 2 : 0)) : 0;
+        if (!REROLL)
+            p.slow_trig[b] = (slow_bits & 1) | committed;
+        else if (roll)
+            p.slow_trig[b] = slow_bits | committed;
+    }
     if (active) {
         p.iters[b] += 1;
         T Jn = roll ? p.Jtry[b] : p.J[b];
@@ -1286,10 +1361,10 @@ __global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, i
     const T alpha = pow2_neg<T>(roll ? idx : 0);
     // the trajectory is overwritten in place, so the choice between the fast trigonometry and
     // the library routine is made up front, from what the evaluate kernel saw on these problems
-    if (__ballot(slow) == 0ull)
-        commit_sweep<T, M, PF, true>(p, Xt, Ut, Kp, kp, alpha, roll);
+    if (!wave_slow)
+        commit_sweep<T, M, PF, REROLL, true>(p, Xt, Ut, Kp, kp, trash, alpha, roll, keep_ok);
     else
-        commit_sweep<T, M, 1, false>(p, Xt, Ut, Kp, kp, alpha, roll);
+        commit_sweep<T, M, 1, REROLL, false>(p, Xt, Ut, Kp, kp, trash, alpha, roll, keep_ok);
 }
 
 // ---------------------------------------------------------------- active-set compaction

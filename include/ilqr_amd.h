@@ -86,7 +86,9 @@ typedef struct ilqr_desc {
                                   its own, so phases of different parts overlap (1..8); 0 = auto */
     int32_t repack_every;      /* ilqr_solve compacts the still-active problems into dense tiles every this many
                                   iterations (needs the larger workspace, see ilqr_workspace_bytes); <= 0 = never */
-    int32_t reserved1;
+    int32_t recompute_states;  /* >= 0: once a step has been committed, the forward kernels roll the previous
+                                  states out again from U instead of reading X (same bits, less traffic);
+                                  < 0: always read X */
     double dt;               /* system.dt (systems.py:30); the solver's own dt argument is unused (ilqr.py:20) */
     double lm_parameter;     /* ilqr.py:30, added to Vxx (ilqr.py:95) */
     double alpha_floor;      /* 1e-4 (ilqr.py:71) or alpha_terminal (cilqr.py:41) */
@@ -134,7 +136,9 @@ int32_t ilqr_num_alphas(const ilqr_handle *h);
 /* attaches device buffers; replaces the attribute assignments of ilqr_demo.py:47-49 */
 int ilqr_bind(ilqr_handle *h, const ilqr_buffers *bufs);
 
-/* J[b] = cost of the current (X, U) for every problem: ilqr.py:108 / :36-46 */
+/* J[b] = cost of the current (X, U) for every problem: ilqr.py:108 / :36-46.
+ * Call it whenever X or U were written by anything but this library: it also tells the
+ * handle that X is no longer known to be the rollout of U. */
 int ilqr_initial_cost(ilqr_handle *h, void *stream);
 /* one backward pass for every non-converged problem: ilqr.py:76-105, cilqr.py:87-139 */
 int ilqr_backward(ilqr_handle *h, void *stream);
