@@ -14,7 +14,8 @@ solves its own B problems (weak scaling, no communication on the solve path); th
 value is the whole-job rate.
 
 Prints ONE JSON line on rank 0 with the metric, a ``roofline`` object for the dominant kernel
-(per-launch HIP-event timings taken inside the timed region) and, at N=1, a ``cpu_baseline``
+(the one with the largest total time; per-launch HIP-event timings taken inside the timed region,
+achieved = the bytes the kernel must move for the problems still iterating / its duration) and, at N=1, a ``cpu_baseline``
 object: the C oracle (a port of the reference's per-problem loop) timed on the host cores on
 a bounded sample of the same workload.
 """
@@ -33,14 +34,17 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
 
 def algorithmic_bytes(N, n, m, w=8):
-    """Per problem and iteration, fp64: what each phase must read and write at least.
-    backward: read X, U, Xref, write K, k.  evaluate: read K, k, X, U, Xref (all step sizes
-    share one read).  commit: write the winning X, U."""
+    """Bytes each kernel must move per problem it works on (w bytes per value), the least the
+    phase decomposition allows: backward reads X, U, Xref and writes K, k; the line search reads
+    K, k, U, Xref and x0 once for all step sizes (the previous states follow from x0 and U);
+    the commit reads K, k, U, x0 and writes the accepted X, U."""
     T = N - 1
+    gains = T * m * n + T * m
     return {
-        "backward": w * (2 * N * n + T * m + T * m * n + T * m),
-        "evaluate": w * (T * m * n + T * m + 2 * N * n + T * m),
-        "commit": w * (N * n + T * m),
+        "backward": w * (2 * N * n + T * m + gains),
+        "evaluate_first": w * (gains + T * m + N * n + n),
+        "evaluate_rest": w * (gains + T * m + N * n + n),
+        "commit": w * (gains + T * m + n + N * n + T * m),
     }
 
 
@@ -107,19 +111,21 @@ def main():
         torch.cuda.synchronize()
 
     def solve_step(events=None):
-        """The phases of ilqr_solve, launched one by one so that events can bracket them."""
+        """The launches of ilqr_solve, issued one by one so that events can bracket them."""
         reset()
         dev.initial_cost()
         for it in range(max_iter):
             if events is not None:
-                e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
                 e[0].record()
                 dev.backward()
                 e[1].record()
-                dev.forward_evaluate()
+                dev.forward_evaluate_stage(0)
                 e[2].record()
-                dev.forward_commit(it)
+                dev.forward_evaluate_stage(1)
                 e[3].record()
+                dev.forward_commit(it)
+                e[4].record()
                 events.append(e)
             else:
                 dev.backward()
@@ -150,13 +156,18 @@ def main():
         dist.all_reduce(iter_sum)
 
     # per-kernel timings from the events of the timed region (this rank)
-    kt = {"backward": [], "evaluate": [], "commit": []}
+    names = ("backward", "evaluate_first", "evaluate_rest", "commit")
+    kt = {k: [] for k in names}
     for e in events:
-        kt["backward"].append(e[0].elapsed_time(e[1]))
-        kt["evaluate"].append(e[1].elapsed_time(e[2]))
-        kt["commit"].append(e[2].elapsed_time(e[3]))
+        for i, k in enumerate(names):
+            kt[k].append(e[i].elapsed_time(e[i + 1]))
     ab = algorithmic_bytes(N, 4, 2, 8 if args.dtype == "f64" else 4)
-    units = {"backward": active, "evaluate": active, "commit": accepted}
+    L_, A_ = dev.forward_mapping()
+    n_alphas = dev.num_alphas()
+    # problems the second line-search stage works on: no improvement among the first L*A step sizes
+    listed = (((ha == -1) | (ha >= L_ * A_)).sum(axis=1).astype(np.int64) if L_ * A_ < n_alphas
+              else np.zeros(max_iter, dtype=np.int64))
+    units = {"backward": active, "evaluate_first": active, "evaluate_rest": listed, "commit": accepted}
     kernels = {}
     for name, ms in kt.items():
         ms = np.array(ms).reshape(args.steps, max_iter)
@@ -169,6 +180,7 @@ def main():
             "total_ms": float(total_ms),
             "achieved_GBs": float(total_bytes / (total_ms * 1e-3) / 1e9) if total_ms > 0 else 0.0,
             "bytes_per_problem": ab[name],
+            "problems_per_launch": float(units[name][live].mean()) if live.any() else 0.0,
         }
     dominant = max(kernels, key=lambda k: kernels[k]["total_ms"])
     traffic = None
@@ -197,7 +209,7 @@ def main():
             "data": "synthetic (seeded Car tracking problems, ilqr_amd.problems.car_batch)",
             "config": {"workload": f"Car n=4 m=2, N={N}, B={B} problems per GPU, maxIter=30, 15 parallel step sizes",
                        "batch_per_gpu": B, "batch_total": B_total, "horizon": N,
-                       "forward_mapping": f"L={dev.desc.lanes_per_problem or 'auto'},A={dev.desc.alphas_per_lane or 'auto'}"},
+                       "forward_mapping": f"L={L_},A={A_} ({'two-stage' if L_ * A_ < n_alphas else 'one stage'})"},
             "mean_iterations_per_solve": float(iter_sum[0].item()) / B_total,
             "converged_fraction": float(iter_sum[1].item()) / B_total,
             "executed_iterations_per_step": float(iter_sum[0].item()),
@@ -209,7 +221,8 @@ def main():
                 "bytes_per_problem_per_launch": ab[dominant],
             },
             "kernels": kernels,
-            "solve_achieved_GBs": float(args.steps * (active * (ab["backward"] + ab["evaluate"]) + accepted * ab["commit"]).sum()
+            "solve_achieved_GBs": float(args.steps * (active * (ab["backward"] + ab["evaluate_first"]) + listed * ab["evaluate_rest"]
+                                                      + accepted * ab["commit"]).sum()
                                         / elapsed / 1e9) * (world if not args.strong else 1),
         }
         if world == 1 and not args.no_cpu_baseline:

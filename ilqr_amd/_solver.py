@@ -221,6 +221,19 @@ class DeviceProblem:
     def forward_evaluate(self):
         _lib.check(self.lib.ilqr_forward_evaluate(self.handle, self.stream()), "ilqr_forward_evaluate")
 
+    def forward_mapping(self):
+        """(lanes per problem, step sizes per lane) of the first line-search stage."""
+        L, A = C.c_int32(0), C.c_int32(0)
+        _lib.check(self.lib.ilqr_forward_mapping(self.handle, C.byref(L), C.byref(A)), "ilqr_forward_mapping")
+        return int(L.value), int(A.value)
+
+    def num_alphas(self):
+        return int(self.lib.ilqr_num_alphas(self.handle))
+
+    def forward_evaluate_stage(self, stage):
+        _lib.check(self.lib.ilqr_forward_evaluate_stage(self.handle, int(stage), self.stream()),
+                   "ilqr_forward_evaluate_stage")
+
     def forward_commit(self, iteration=0):
         _lib.check(self.lib.ilqr_forward_commit(self.handle, int(iteration), self.stream()),
                    "ilqr_forward_commit")

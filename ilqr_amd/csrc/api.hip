@@ -4,6 +4,7 @@
 #include "host.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -72,8 +73,11 @@ struct PartState {
     int parity = 0;   // working set in use once packed
 };
 
+// mode REPACK_CARRY: build the next working set; REPACK_RETIRE_ALL: states and inputs of every
+// problem still in the working set go back to the caller's buffers; REPACK_RETIRE_LIVE: gains of
+// the problems that never converged go back to the caller's buffers.
 template <typename T>
-static hipError_t repack_launch(ilqr_handle *h, PartState &ps, bool final_pass, hipStream_t s) {
+static hipError_t repack_launch(ilqr_handle *h, PartState &ps, int mode, hipStream_t s) {
     const ilqr_desc &d = h->ctx.d;
     const ilqr_buffers &b = h->ctx.b;
     const WorkLayout wl = work_layout(d, true);
@@ -90,39 +94,47 @@ static hipError_t repack_launch(ilqr_handle *h, PartState &ps, bool final_pass, 
     int32_t *tile_offset = (int32_t *)(work + wl.tile_offset) + tile0;
     int32_t *nslots_new = (int32_t *)(work + wl.nslots) + ps.index * 2 + q;
     const int32_t *map_old = ps.ctx.ws.slot2orig, *nslots_old = ps.ctx.ws.nslots;
+    const bool carry = mode == REPACK_CARRY;
 
-    if (!final_pass) {
+    if (carry) {
         hipLaunchKernelGGL(repack_count_kernel, dim3(ntiles), dim3(64), 0, s, map_old, nslots_old, ps.ctx.count, ps.ctx.first,
                            b.converged, tile_count);
         hipLaunchKernelGGL(repack_scan_kernel, dim3(1), dim3(1024), 0, s, (const int32_t *)tile_count, tile_offset, ntiles, nslots_new);
     }
     RepackArgs<T> a;
     a.narr = 0;
+    int chunks = 0;
     auto add = [&](const void *src, T *dst_active, T *dst_retire, int rows) {
         if (!dst_active && !dst_retire) return;
         a.arr[a.narr].src = (const T *)src;
         a.arr[a.narr].dst_active = dst_active;
         a.arr[a.narr].dst_retire = dst_retire;
         a.arr[a.narr].rows = rows;
+        a.arr[a.narr].chunk0 = chunks;
+        chunks += (rows + REPACK_CHUNK - 1) / REPACK_CHUNK;
         ++a.narr;
     };
     const bool pk = ps.packed;
     // current arrays: the caller's buffers until the first repack, a working set afterwards
     const void *Xc = pk ? ps.ctx.ws.X : part_rel(b.X, N * n), *Uc = pk ? ps.ctx.ws.U : part_rel(b.U, T1 * m);
     const void *Rc = pk ? ps.ctx.ws.Xref : part_rel(b.Xref, N * n);
-    const void *Kc = pk ? ps.ctx.ws.K : part_rel(b.K, T1 * m * n), *kc = pk ? ps.ctx.ws.k : part_rel(b.k, T1 * m);
     const void *Cc = pk ? ps.ctx.ws.centers : part_rel(b.centers, N * 2), *Dc = pk ? ps.ctx.ws.radius : part_rel(b.radius, N);
-    // retired problems go to their own place in the caller's buffers; before the first repack
-    // they are there already
-    add(Xc, final_pass ? nullptr : set_ptr(q, 0, N * n), pk ? (T *)b.X : nullptr, N * n);
-    add(Uc, final_pass ? nullptr : set_ptr(q, 1, T1 * m), pk ? (T *)b.U : nullptr, T1 * m);
-    add(Rc, final_pass ? nullptr : set_ptr(q, 2, N * n), nullptr, N * n);
-    if (barrier) {
-        add(Cc, final_pass ? nullptr : set_ptr(q, 3, N * 2), nullptr, N * 2);
-        add(Dc, final_pass ? nullptr : set_ptr(q, 4, N), nullptr, N);
+    if (mode == REPACK_RETIRE_LIVE) {
+        add(ps.ctx.ws.K, nullptr, (T *)b.K, T1 * m * n);
+        add(ps.ctx.ws.k, nullptr, (T *)b.k, T1 * m);
+    } else {
+        // retired problems go to their own place in the caller's buffers; before the first repack
+        // they are there already
+        add(Xc, carry ? set_ptr(q, 0, N * n) : nullptr, pk ? (T *)b.X : nullptr, N * n);
+        add(Uc, carry ? set_ptr(q, 1, T1 * m) : nullptr, pk ? (T *)b.U : nullptr, T1 * m);
+        if (carry) {
+            add(Rc, set_ptr(q, 2, N * n), nullptr, N * n);
+            if (barrier) {
+                add(Cc, set_ptr(q, 3, N * 2), nullptr, N * 2);
+                add(Dc, set_ptr(q, 4, N), nullptr, N);
+            }
+        }
     }
-    add(Kc, nullptr, pk ? (T *)b.K : nullptr, T1 * m * n);
-    add(kc, nullptr, pk ? (T *)b.k : nullptr, T1 * m);
     a.slot2orig_old = map_old;
     a.slot2orig_new = map_new;
     a.nslots_old = nslots_old;
@@ -130,10 +142,10 @@ static hipError_t repack_launch(ilqr_handle *h, PartState &ps, bool final_pass, 
     a.converged = b.converged;
     a.B = ps.ctx.count;
     a.first = ps.ctx.first;
-    a.retire_all = final_pass ? 1 : 0;
-    if (a.narr > 0) hipLaunchKernelGGL((repack_move_kernel<T>), dim3(ntiles), dim3(64), 0, s, a);
+    a.mode = mode;
+    if (a.narr > 0) hipLaunchKernelGGL((repack_move_kernel<T>), dim3(ntiles, chunks), dim3(64), 0, s, a);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess || final_pass) return e;
+    if (e != hipSuccess || !carry) return e;
     ps.ctx.ws.X = set_ptr(q, 0, N * n);
     ps.ctx.ws.U = set_ptr(q, 1, T1 * m);
     ps.ctx.ws.Xref = set_ptr(q, 2, N * n);
@@ -148,9 +160,23 @@ static hipError_t repack_launch(ilqr_handle *h, PartState &ps, bool final_pass, 
     return hipSuccess;
 }
 
-static int repack(ilqr_handle *h, PartState &ps, bool final_pass, hipStream_t s) {
-    if (final_pass && !ps.packed) return ILQR_OK; // everything is in the caller's buffers already
-    return hip_rc(h->ctx.d.dtype == ILQR_F64 ? repack_launch<double>(h, ps, final_pass, s) : repack_launch<float>(h, ps, final_pass, s));
+static int repack(ilqr_handle *h, PartState &ps, int mode, hipStream_t s) {
+    return hip_rc(h->ctx.d.dtype == ILQR_F64 ? repack_launch<double>(h, ps, mode, s) : repack_launch<float>(h, ps, mode, s));
+}
+
+// End of a solve whose part was compacted: everything goes back to the caller's buffers.
+static int unpack(ilqr_handle *h, PartState &ps, hipStream_t s) {
+    if (!ps.packed) return ILQR_OK; // everything is in the caller's buffers already
+    int rc = repack(h, ps, REPACK_RETIRE_ALL, s);
+    if (rc != ILQR_OK) return rc;
+    // gains of the converged problems: one backward pass over them in the caller's buffers (it
+    // also writes gains for their tile neighbours that never converged; the next step replaces those)
+    HostCtx c = ps.ctx;
+    c.ws = HostCtx::WorkSet();
+    c.select_converged = true;
+    rc = hip_rc(h->ops->backward(c, 0, s));
+    if (rc != ILQR_OK) return rc;
+    return repack(h, ps, REPACK_RETIRE_LIVE, s);
 }
 
 extern "C" {
@@ -262,6 +288,13 @@ size_t ilqr_workspace_bytes(const ilqr_handle *h) { return h ? work_layout(h->ct
 
 int32_t ilqr_num_alphas(const ilqr_handle *h) { return h ? h->ctx.n_alphas : 0; }
 
+int ilqr_forward_mapping(const ilqr_handle *h, int32_t *lanes_per_problem, int32_t *alphas_per_lane) {
+    if (!h || !lanes_per_problem || !alphas_per_lane) return ILQR_ERR_INVALID;
+    *lanes_per_problem = h->ctx.L;
+    *alphas_per_lane = h->ctx.A;
+    return ILQR_OK;
+}
+
 int ilqr_bind(ilqr_handle *h, const ilqr_buffers *b) {
     if (!h || !b) return ILQR_ERR_INVALID;
     if (!b->X || !b->U || !b->Xref || !b->K || !b->k || !b->J || !b->converged || !b->iters || !b->alpha_idx || !b->work)
@@ -293,6 +326,14 @@ int ilqr_backward(ilqr_handle *h, void *stream) {
 int ilqr_forward_evaluate(ilqr_handle *h, void *stream) {
     REQUIRE_BOUND(h);
     return hip_rc(h->ops->evaluate(h->ctx, 0, (hipStream_t)stream));
+}
+
+int ilqr_forward_evaluate_stage(ilqr_handle *h, int32_t stage, void *stream) {
+    REQUIRE_BOUND(h);
+    if (stage != 0 && stage != 1) return ILQR_ERR_INVALID;
+    HostCtx c = h->ctx;
+    c.eval_stages = stage == 0 ? 1 : 2;
+    return hip_rc(h->ops->evaluate(c, 0, (hipStream_t)stream));
 }
 
 int ilqr_forward_commit(ilqr_handle *h, int32_t iteration, void *stream) {
@@ -356,13 +397,14 @@ int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream) {
     // backward pass and the commit are bandwidth-bound; a token (an event chain) lets only one
     // part run its line search at a time, which pushes the parts into opposite phases.
     int prev = -1;
+    const bool use_token = getenv("ILQR_NO_TOKEN") == nullptr;
     for (int it = 0; it < max_iter && rc == ILQR_OK; ++it)
         for (int s = 0; s < np && rc == ILQR_OK; ++s) {
             // from the second iteration on, every active problem's X is this library's rollout of U
             part[s].ctx.reroll = it > 0 && h->ctx.d.recompute_states >= 0;
-            if (h->repack_every > 0 && it > 0 && it % h->repack_every == 0) rc = repack(h, part[s], false, st[s]);
+            if (h->repack_every > 0 && it >= 2 * h->repack_every && it % h->repack_every == 0) rc = repack(h, part[s], REPACK_CARRY, st[s]);
             if (rc == ILQR_OK) rc = hip_rc(h->ops->backward(part[s].ctx, 0, st[s]));
-            if (np > 1) {
+            if (np > 1 && use_token) {
                 if (rc == ILQR_OK && prev >= 0) rc = hip_rc(hipStreamWaitEvent(st[s], h->join_event[prev], 0));
                 if (rc == ILQR_OK) rc = hip_rc(h->ops->evaluate(part[s].ctx, 0, st[s]));
                 if (rc == ILQR_OK) rc = hip_rc(hipEventRecord(h->join_event[s], st[s]));
@@ -373,7 +415,7 @@ int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream) {
             if (rc == ILQR_OK) rc = hip_rc(h->ops->commit(part[s].ctx, it, st[s]));
         }
     for (int s = 0; s < np; ++s) {
-        if (rc == ILQR_OK) rc = repack(h, part[s], true, st[s]); // retire what is still in a working set
+        if (rc == ILQR_OK) rc = unpack(h, part[s], st[s]); // retire what is still in a working set
         if (np > 1) {
             e = hipEventRecord(h->join_event[s], st[s]);
             if (e == hipSuccess) e = hipStreamWaitEvent(user, h->join_event[s], 0);

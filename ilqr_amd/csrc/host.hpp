@@ -22,6 +22,8 @@ struct HostCtx {
     // (true between a commit and the next change of the buffers): the forward kernels may then
     // roll the previous states out again instead of reading them
     bool reroll = false;
+    bool select_converged = false; // backward pass: recompute the gains of the converged problems
+    int eval_stages = 3;           // line search: bit 0 = stage one, bit 1 = stage two (see evaluate_kernel)
     // working set of ilqr_solve's active-set compaction: when `slot2orig` is set, the tiled
     // arrays below replace the bound ones (they are already relative to this part and hold
     // *nslots problems in slot order) and the per-problem arrays are indexed through the map
@@ -145,6 +147,9 @@ template <typename T, int NX, int NU> static Params<T, NX, NU> make_params(const
     p.B = c.count;
     p.N = d.N;
     p.n_alphas = c.n_alphas;
+    p.select_converged = c.select_converged ? 1 : 0;
+    p.slots_lo = -1;
+    p.slots_hi = 0x7fffffff;
     p.dt = (T)d.dt;
     p.lm = (T)d.lm_parameter;
     p.lambda = (T)d.input_limit_lambda;
@@ -222,22 +227,28 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
     template <bool BARRIER, int L, int A> static hipError_t eval_la(const HostCtx &c, hipStream_t s) {
         return c.reroll ? eval_lar<BARRIER, L, A, true>(c, s) : eval_lar<BARRIER, L, A, false>(c, s);
     }
+    template <bool BARRIER, int L, int A, bool REROLL>
+    static hipError_t eval_first(const HostCtx &c, hipStream_t s, int first_end, int slots_lo, int slots_hi) {
+        auto p = make_params<T, NX, NU>(c);
+        p.slots_lo = slots_lo;
+        p.slots_hi = slots_hi;
+        const int ppw = 64 / L;                    // problems per wave
+        const long most = slots_hi < c.count ? slots_hi : c.count;
+        const long waves = (most + ppw - 1) / ppw;
+        const int blocks = (int)((waves + 3) / 4); // 4 waves per workgroup
+        hipLaunchKernelGGL((evaluate_kernel<T, M, DIAG, BARRIER, L, A, REROLL>), dim3(blocks), dim3(256), 0, s, p, first_end);
+        return hipGetLastError();
+    }
     template <bool BARRIER, int L, int A, bool REROLL> static hipError_t eval_lar(const HostCtx &c, hipStream_t s) {
         auto p = make_params<T, NX, NU>(c);
         const int first_end = c.n_alphas < L * A ? c.n_alphas : L * A;
         const bool two = first_end < c.n_alphas;
-        if (two) {
-            hipError_t e = hipMemsetAsync(p.list_count, 0, sizeof(int32_t), s);
+        if (c.eval_stages & 1) {
+            hipError_t e = two ? hipMemsetAsync(p.list_count, 0, sizeof(int32_t), s) : hipSuccess;
+            if (e == hipSuccess) e = eval_stage_one<BARRIER, L, A, REROLL>(c, s, first_end);
             if (e != hipSuccess) return e;
         }
-        {
-            const int ppw = 64 / L;                    // problems per wave
-            const long waves = ((long)c.count + ppw - 1) / ppw;
-            const int blocks = (int)((waves + 3) / 4); // 4 waves per workgroup
-            hipLaunchKernelGGL((evaluate_kernel<T, M, DIAG, BARRIER, L, A, REROLL>), dim3(blocks), dim3(256), 0, s, p, first_end);
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess || !two) return e;
-        }
+        if (!two || !(c.eval_stages & 2)) return hipSuccess;
         // the length of the list is only known on the device: the grid covers the worst case and
         // the waves beyond the list leave at once
         constexpr int L2 = M::NX > 8 ? 16 : 8;
@@ -245,6 +256,25 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
         const int blocks = (int)(((long)c.count + ppw - 1) / ppw); // one wave per workgroup
         hipLaunchKernelGGL((evaluate_listed_kernel<T, M, DIAG, BARRIER, L2, REROLL>), dim3(blocks), dim3(64), 0, s, p, first_end, c.n_alphas);
         return hipGetLastError();
+    }
+    template <bool BARRIER, int L, int A, bool REROLL> static hipError_t eval_stage_one(const HostCtx &c, hipStream_t s, int first_end) {
+        hipError_t e;
+        if constexpr (M::NX <= 8 && L == 1 && A == 8) {
+            // Compacted working set: the number of slots shrinks during the solve and is only
+            // known on the device.  With fewer than one tile per SIMD, one lane per problem leaves
+            // SIMDs idle while each wave still walks its 8 candidates in sequence, so mappings with
+            // more lanes per problem take over; all are launched and each looks at the count.
+            if (c.ws.slot2orig != nullptr) {
+                e = eval_first<BARRIER, 1, 8, REROLL>(c, s, first_end, 40960, 0x7fffffff);
+                if (e == hipSuccess) e = eval_first<BARRIER, 2, 4, REROLL>(c, s, first_end, 20480, 40960);
+                if (e == hipSuccess) e = eval_first<BARRIER, 4, 2, REROLL>(c, s, first_end, -1, 20480);
+            } else {
+                e = eval_first<BARRIER, L, A, REROLL>(c, s, first_end, -1, 0x7fffffff);
+            }
+        } else {
+            e = eval_first<BARRIER, L, A, REROLL>(c, s, first_end, -1, 0x7fffffff);
+        }
+        return e;
     }
     template <bool BARRIER> static hipError_t eval_b(const HostCtx &c, hipStream_t s) {
         const int key = c.L * 100 + c.A;

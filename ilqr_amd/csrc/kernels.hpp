@@ -132,6 +132,8 @@ template <typename T, int NX, int NU> struct Params {
     int32_t hist_stride; // problems per history row (the whole batch, also when this launch covers a part)
     int32_t B, N;
     int32_t n_alphas;
+    int32_t slots_lo, slots_hi; // evaluate_kernel runs only if slots_lo < number of slots <= slots_hi
+    int32_t select_converged; // backward pass only: work on the converged problems instead of the active ones
     T dt, lm, lambda, mu, delta, vlo, vhi;
     T Q[NX * NX], R[NU * NU], Qf[NX * NX];
     T Q2[NX * NX], R2[NU * NU], Qf2[NX * NX];
@@ -763,7 +765,8 @@ __global__ __launch_bounds__(64) void backward_kernel(Params<T, M::NX, M::NU> p)
     if (nsl <= 0) return;
     const bool valid = b0 < nsl;
     const int o = orig_of(p, valid ? b0 : nsl - 1);
-    const bool active = valid && p.converged[o] == 0;
+    // normally the problems still iterating; at the end of a solve with compaction, the converged ones
+    const bool active = valid && (p.converged[o] == 0) != (p.select_converged != 0);
     if (__ballot(active) == 0ull) return;
     const int T1 = p.N - 1;
     constexpr bool BARRIER_ = (CONSTR & 2) != 0;
@@ -970,6 +973,9 @@ __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T,
     const int pl = lane / L, al = lane % L;
     const int g = wave * PPW + pl;
     const int nsl = slot_count(p);
+    // with active-set compaction the host launches several mappings and the one whose range
+    // holds the current number of slots does the work
+    if (nsl <= p.slots_lo || nsl > p.slots_hi) return;
     if (wave * PPW >= nsl) return;
     const bool valid = g < nsl;
     const int b = valid ? g : nsl - 1; // slot
@@ -1372,8 +1378,13 @@ __global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, i
 // is rare because problems converge independently.  ilqr_solve therefore repacks every few
 // iterations: the still-active problems of the current working set are copied, in order, into
 // dense tiles of a second working set, and the problems that converged since the last repack
-// are retired, i.e. copied to their place in the caller's buffers.  Three tiny kernels build
-// the slot map; one streaming kernel moves the rows.
+// are retired, i.e. their states and inputs are copied to their place in the caller's buffers.
+// Three tiny kernels build the slot map; one streaming kernel moves the rows.  The gains K, k are
+// dead between a commit and the next backward pass, so they are never moved: the backward pass
+// writes them for the working set, and at the end of the solve the gains of the problems that
+// never converged are retired while those of the converged problems are computed once more, in
+// place, from their final trajectories (the trajectory has not changed since their last
+// backward pass, so these are the same bits).
 
 // one wave per tile of the current working set: number of active problems in the tile
 static __global__ __launch_bounds__(64) void repack_count_kernel(const int32_t *slot2orig, const int32_t *nslots, int B, int first,
@@ -1414,10 +1425,16 @@ static __global__ __launch_bounds__(1024) void repack_scan_kernel(const int32_t 
 
 template <typename T> struct RepackArray {
     const T *src;   // current working set, slot order
-    T *dst_active;  // next working set, slot order (null: array is not carried over, e.g. the gains)
+    T *dst_active;  // next working set, slot order (null: array is not carried over)
     T *dst_retire;  // caller's buffer, problem order (null: the data is already in place there)
     int rows;       // values per problem
+    int chunk0;     // first chunk (REPACK_CHUNK rows each) of this array in the grid's y range
 };
+constexpr int REPACK_CHUNK = 32;
+// what happens to the problems of the current working set
+constexpr int REPACK_CARRY = 0;       // active: carried over to the next working set; converged: retired
+constexpr int REPACK_RETIRE_ALL = 1;  // every problem is retired (end of the solve)
+constexpr int REPACK_RETIRE_LIVE = 2; // only the problems that never converged are retired (end of the solve: their gains)
 template <typename T> struct RepackArgs {
     RepackArray<T> arr[7];
     int narr;
@@ -1428,10 +1445,12 @@ template <typename T> struct RepackArgs {
     const int32_t *converged;     // per problem, global index
     int B;                        // problems of this part (slots before the first repack)
     int first;                    // global index of the part's first problem
-    int retire_all;               // final pass: every slot is retired, none carried over
+    int mode;                     // REPACK_*
 };
 
-// one wave per tile of the current working set; streams every row of the tile once
+// blockIdx.x: tile of the current working set; blockIdx.y: a chunk of REPACK_CHUNK rows of one of
+// the arrays.  Every wave moves its chunk for the 64 problems of the tile with all its loads in
+// flight together, so the copy runs at memory speed.
 template <typename T> __global__ __launch_bounds__(64) void repack_move_kernel(RepackArgs<T> a) {
     const int tile = blockIdx.x, lane = threadIdx.x;
     const int s = tile * 64 + lane;
@@ -1439,32 +1458,31 @@ template <typename T> __global__ __launch_bounds__(64) void repack_move_kernel(R
     if (tile * 64 >= nsl) return;
     const bool valid = s < nsl;
     const int o = valid ? (a.slot2orig_old ? a.slot2orig_old[s] : s + a.first) : 0;
-    const bool act = valid && !a.retire_all && a.converged[o] == 0;
-    const bool ret = valid && !act;
+    const bool live = valid && a.converged[o] == 0;
+    const bool act = live && a.mode == REPACK_CARRY;
+    const bool ret = valid && (a.mode == REPACK_RETIRE_ALL || (a.mode == REPACK_CARRY && !live) || (a.mode == REPACK_RETIRE_LIVE && live));
     const unsigned long long m = __ballot(act);
     const int ns = act ? a.tile_offset[tile] + (int)__popcll(m & ((1ull << lane) - 1ull)) : 0;
-    if (act) a.slot2orig_new[ns] = o;
-    for (int q = 0; q < a.narr; ++q) {
-        const RepackArray<T> r = a.arr[q];
-        const T *src = r.src + (size_t)tile * r.rows * TILE + lane;
-        T *da = (act && r.dst_active) ? r.dst_active + (size_t)(ns >> 6) * r.rows * TILE + (ns & 63) : nullptr;
-        T *dr = (ret && r.dst_retire) ? r.dst_retire + (size_t)(o >> 6) * r.rows * TILE + (o & 63) : nullptr;
-        T *dst = da ? da : dr;
-        if (__ballot(dst != nullptr) == 0ull) continue;
-        int i = 0;
-        for (; i + 4 <= r.rows; i += 4) {
-            T v0 = src[(i + 0) * TILE], v1 = src[(i + 1) * TILE], v2 = src[(i + 2) * TILE], v3 = src[(i + 3) * TILE];
-            if (dst) {
-                dst[(i + 0) * TILE] = v0;
-                dst[(i + 1) * TILE] = v1;
-                dst[(i + 2) * TILE] = v2;
-                dst[(i + 3) * TILE] = v3;
-            }
-        }
-        for (; i < r.rows; ++i) {
-            T v = src[i * TILE];
-            if (dst) dst[i * TILE] = v;
-        }
+    if (act && blockIdx.y == 0) a.slot2orig_new[ns] = o;
+    int q = 0;
+    while (q + 1 < a.narr && (int)blockIdx.y >= a.arr[q + 1].chunk0) ++q;
+    const RepackArray<T> r = a.arr[q];
+    const int i0 = ((int)blockIdx.y - r.chunk0) * REPACK_CHUNK;
+    T *dst = (act && r.dst_active) ? r.dst_active + (size_t)(ns >> 6) * r.rows * TILE + (ns & 63)
+             : (ret && r.dst_retire) ? r.dst_retire + (size_t)(o >> 6) * r.rows * TILE + (o & 63)
+                                     : nullptr;
+    if (__ballot(dst != nullptr) == 0ull) return;
+    const T *src = r.src + (size_t)tile * r.rows * TILE + lane;
+    T v[REPACK_CHUNK];
+#pragma unroll
+    for (int j = 0; j < REPACK_CHUNK; ++j) {
+        const int i = i0 + j < r.rows ? i0 + j : r.rows - 1; // no branch around the loads
+        v[j] = src[(size_t)i * TILE];
+    }
+    if (dst) {
+#pragma unroll
+        for (int j = 0; j < REPACK_CHUNK; ++j)
+            if (i0 + j < r.rows) dst[(size_t)(i0 + j) * TILE] = v[j];
     }
 }
 

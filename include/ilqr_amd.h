@@ -132,6 +132,9 @@ void ilqr_destroy(ilqr_handle *h);
 size_t ilqr_workspace_bytes(const ilqr_handle *h);
 /* number of line-search candidates the handle uses (15 for ilqr.py, 8 for cilqr.py defaults) */
 int32_t ilqr_num_alphas(const ilqr_handle *h);
+/* the forward mapping in use (the descriptor's, or the one chosen for 0 = auto): the first stage
+ * of the line search rolls out lanes_per_problem * alphas_per_lane step sizes per problem */
+int ilqr_forward_mapping(const ilqr_handle *h, int32_t *lanes_per_problem, int32_t *alphas_per_lane);
 
 /* attaches device buffers; replaces the attribute assignments of ilqr_demo.py:47-49 */
 int ilqr_bind(ilqr_handle *h, const ilqr_buffers *bufs);
@@ -149,6 +152,13 @@ int ilqr_backward(ilqr_handle *h, void *stream);
 int ilqr_forward(ilqr_handle *h, int32_t iteration, void *stream);
 int ilqr_forward_evaluate(ilqr_handle *h, void *stream);
 int ilqr_forward_commit(ilqr_handle *h, int32_t iteration, void *stream);
+/* ilqr_forward_evaluate in its two launches, for callers that time or schedule them apart:
+ * stage 0 rolls out the first lanes_per_problem*alphas_per_lane step sizes for every problem
+ * and lists the problems that found no improvement among them; stage 1 rolls out the remaining
+ * step sizes for the listed problems (a no-op when stage 0 covered all of them).  Stage 1 is only
+ * meaningful directly after stage 0 of the same line search (ilqr.py:53-74 walks the same step
+ * sizes in one loop). */
+int ilqr_forward_evaluate_stage(ilqr_handle *h, int32_t stage, void *stream);
 /* iterative_LQR.__call__ (ilqr.py:107-114): initial cost, then max_iter x
  * (backward, forward); converged problems are skipped on the device. */
 int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream);

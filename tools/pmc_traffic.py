@@ -8,34 +8,45 @@ Units and corrections (gfx950): both counters are in KiB; FETCH_SIZE counts 64 B
 request, so a coalesced streaming read reports exactly half its bytes and is doubled here
 (checked in the same run on cost_kernel, a pure streaming read of X, U and Xref with the access
 shape of all solver kernels: 8 B per lane, 512 B per wave instruction); WRITE_SIZE is exact for
-these stores (checked on relayout_kernel).  Reported per launch for the launches in which the
-whole batch is active (the maximum over launches).
+these stores (checked on relayout_kernel).  Reported per launch, as the mean over the launches
+of one bench.py step (all template variants of a kernel together), under the names bench.py uses.
 """
+import collections
+import csv
+import glob
 import json
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from pmc_summary import summarize  # noqa: E402
+NAMES = (("backward_kernel", "backward"), ("evaluate_listed_kernel", "evaluate_rest"), ("evaluate_kernel", "evaluate_first"),
+         ("commit_kernel", "commit"), ("cost_kernel", "cost"), ("relayout_kernel", "relayout"))
+
+
+def per_launch(directory, counter, scale):
+    acc = collections.defaultdict(float)
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] != counter:
+                continue
+            key = next((k for sub, k in NAMES if sub in r["Kernel_Name"]), None)
+            if key:
+                acc[(key, r["Dispatch_Id"])] += float(r["Counter_Value"]) * scale
+    out = collections.defaultdict(list)
+    for (key, _), v in acc.items():
+        out[key].append(v)
+    return out
 
 
 def main():
     fetch_dir, write_dir = sys.argv[1], sys.argv[2]
     out = sys.argv[3] if len(sys.argv) > 3 else None
-    acc = summarize([fetch_dir, write_dir])
+    rd = per_launch(fetch_dir, "FETCH_SIZE", 2.0 * 1024.0)
+    wr = per_launch(write_dir, "WRITE_SIZE", 1024.0)
     res = {}
-    for kernel, ctr in acc.items():
-        if "FETCH_SIZE" not in ctr or "WRITE_SIZE" not in ctr:
-            continue
-        key = kernel.split("<")[0].replace("_kernel", "")
-        rd = 2.0 * max(ctr["FETCH_SIZE"]) * 1024.0
-        wr = max(ctr["WRITE_SIZE"]) * 1024.0
-        entry = {"kernel": kernel, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
-                 "bytes_per_launch": rd + wr, "launches": len(ctr["FETCH_SIZE"]),
-                 "mean_bytes_per_launch": 2048.0 * sum(ctr["FETCH_SIZE"]) / len(ctr["FETCH_SIZE"])
-                 + 1024.0 * sum(ctr["WRITE_SIZE"]) / len(ctr["WRITE_SIZE"])}
-        if key not in res or entry["bytes_per_launch"] > res[key]["bytes_per_launch"]:
-            res[key] = entry
+    for key in rd:
+        r, w = rd[key], wr.get(key, [0.0])
+        res[key] = {"launches": len(r), "read_bytes_per_launch": sum(r) / len(r), "write_bytes_per_launch": sum(w) / len(w),
+                    "bytes_per_launch": sum(r) / len(r) + sum(w) / len(w), "max_bytes_per_launch": max(r) + max(w)}
     txt = json.dumps(res, indent=1)
     print(txt)
     if out:
