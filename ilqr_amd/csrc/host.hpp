@@ -4,7 +4,9 @@
 #include "../../include/ilqr_amd.h"
 #include "kernels.hpp"
 
+#include <cstdlib>
 #include <limits>
+#include <type_traits>
 
 namespace ilqr {
 
@@ -34,10 +36,10 @@ struct HostCtx {
     } ws;
 };
 
-// Layout of the caller-provided `work` buffer (byte offsets).  The first six regions always
+// Layout of the caller-provided `work` buffer (byte offsets).  The first seven regions always
 // exist; the rest only with active-set compaction.
 struct WorkLayout {
-    size_t jtry = 0, slow = 0, counters = 0, list = 0, list_count = 0, trash = 0;
+    size_t jtry = 0, slow = 0, counters = 0, list = 0, list_count = 0, trash = 0, redo = 0;
     size_t map[2] = {0, 0}, tile_count = 0, tile_offset = 0, nslots = 0;
     size_t set[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}; // X, U, Xref, centers, radius of the two working sets
     size_t Kw = 0, kw = 0;
@@ -60,6 +62,7 @@ static inline WorkLayout work_layout(const ilqr_desc &d, bool compaction) {
     w.list = take(Bp * 4);          // line-search stage two: slots still without a winner
     w.list_count = take(tiles * 4); // their number, one counter per possible first tile of a part
     w.trash = take(Bp * e);         // one value per lane: sink of the stores of lanes that keep their trajectory
+    w.redo = take((size_t)d.B * 4); // per problem: repeat the backward pass with the fallback solve
     if (compaction) {
         const size_t N = d.N, T1 = d.N - 1, n = d.n, m = d.m;
         const bool barrier = (d.constraint_mode & ILQR_CONSTR_BARRIER) != 0;
@@ -131,6 +134,7 @@ template <typename T, int NX, int NU> static Params<T, NX, NU> make_params(const
     p.list = (int32_t *)((char *)b.work + wl.list) + c.first;
     p.list_count = (int32_t *)((char *)b.work + wl.list_count) + tile0;
     p.trash = (T *)((char *)b.work + wl.trash) + c.first;
+    p.redo = flat((int32_t *)((char *)b.work + wl.redo));
     p.J = flat((T *)b.J);
     p.Jtry = flat((T *)((char *)b.work + wl.jtry));
     p.slow_trig = flat((int32_t *)((char *)b.work + wl.slow));
@@ -214,6 +218,19 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
     }
     static hipError_t backward(const HostCtx &c, int, hipStream_t s) {
         const int mode = c.d.constraint_mode & 3;
+        if constexpr (std::is_same<T, double>::value && std::is_same<M, LtvModelT<double, 12, 4>>::value && DIAG) {
+            // one wave per problem on the fp64 matrix unit (kernels.hpp); the lane-per-problem
+            // kernel remains for the box-QP mode and as the cross-check (ILQR_LTV_GENERIC=1)
+            static const bool generic = getenv("ILQR_LTV_GENERIC") != nullptr;
+            if (mode == 0 && !generic) {
+                auto p = make_params<T, NX, NU>(c);
+                const int tiles = (c.count + 63) / 64;
+                const int blocks = ((tiles + 7) / 8) * 8 * 64;
+                hipLaunchKernelGGL(ltv12x4_backward_mfma_kernel<false>, dim3(blocks), dim3(64), 0, s, p);
+                hipLaunchKernelGGL(ltv12x4_backward_mfma_kernel<true>, dim3(blocks), dim3(64), 0, s, p);
+                return hipGetLastError();
+            }
+        }
         if constexpr (M::HAS_BARRIER) {
             if (mode == 2) return backward_c<2>(c, s);
             if (mode == 3) return backward_c<3>(c, s);
@@ -301,6 +318,16 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
         }
     }
     static hipError_t evaluate(const HostCtx &c, int, hipStream_t s) {
+        if constexpr (std::is_same<T, double>::value && std::is_same<M, LtvModelT<double, 12, 4>>::value && DIAG) {
+            // all step sizes of a problem at once on the fp64 matrix unit (kernels.hpp); a single stage
+            static const bool generic = getenv("ILQR_LTV_GENERIC") != nullptr;
+            if (!barrier_on(c) && c.n_alphas <= 16 && !generic) {
+                if (!(c.eval_stages & 1)) return hipSuccess;
+                auto p = make_params<T, NX, NU>(c);
+                hipLaunchKernelGGL(ltv12x4_evaluate_mfma_kernel, dim3((c.count + 15) / 16), dim3(1024), 0, s, p);
+                return hipGetLastError();
+            }
+        }
         if constexpr (M::HAS_BARRIER) {
             if (barrier_on(c)) return eval_b<true>(c, s);
         }

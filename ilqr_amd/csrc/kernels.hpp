@@ -94,6 +94,9 @@ template <> __device__ __forceinline__ float inf_<float>() { return __builtin_hu
 // single base pointer plus small constant offsets, and every access is a full
 // 512-byte (fp64) row.
 constexpr int TILE = 64;
+#ifndef LTV_SYNC_EVERY
+#define LTV_SYNC_EVERY 4
+#endif
 #ifndef EVAL_MIN_WAVES
 #define EVAL_MIN_WAVES 1
 #endif
@@ -123,6 +126,7 @@ template <typename T, int NX, int NU> struct Params {
     // before stage one, the stage-one kernel appends)
     int32_t *list;
     int32_t *list_count;
+    int32_t *redo; // per problem: the backward pass must be repeated with the pivoted-LU solve (n = 12 model)
     T *trash; // 64 values per tile: where lanes that must not change their trajectory store (commit, REROLL)
     const T *centers, *radius;
     const T *ltvA, *ltvB;
@@ -788,6 +792,161 @@ __global__ __launch_bounds__(64) void backward_kernel(Params<T, M::NX, M::NU> p)
     if (active && status != 0 && p.status) p.status[o] |= status;
 }
 
+// ---------------------------------------------------------------- backward pass, n = 12, m = 4, fp64
+// One lane per problem does not work for the 12-state model: Vxx, the products with the
+// Jacobians and the Q-terms are a few hundred live fp64 values per lane.  Here one wave owns one
+// problem and the matrix products run on the fp64 matrix unit (v_mfma_f64_16x16x4): with
+// F = [A_t | B_t] (12 x 16), all second-order Q-terms are one 16 x 16 matrix G = F' (Vxx + lm I) F
+// = [[Qxx - lxx, Qxu], [Qux, Quu - luu]] (ilqr.py:95-98).
+//
+// Register layouts of a 16 x 16 tile M over the wave, lane = 16 g + c:
+//   D-layout: register r of lane (c, g) = M[g + 4 r][c]   (what the instruction returns)
+//   T-layout: register r of lane (c, g) = M[c][g + 4 r]   (the D-layout of M')
+// The instruction's A operand of its k-th call is the T-layout register k of the left factor,
+// its B operand the D-layout register k of the right factor, so a result feeds the next
+// product directly, and swapping the two operands returns the transposed layout:
+//   D(M N) = mfma(A = T(M), B = D(N)),   T(M N) = mfma(A = D(N), B = T(M)).
+// Rows 12..15 of F are zero (the fourth call of each product is skipped).  Vxx lives in
+// T-layout; W = Vhat F comes out in D-layout; G is computed twice, in T-layout (its x-x block
+// plus K'Qux, one more call, is the next Vxx, already in T-layout) and in D-layout (whose last
+// register holds Qux[g][c] and Quu[g][c-12] exactly where the rank-4 update and the gains need
+// them).  The 4 x 4 solve is done redundantly by every lane for its own column of K.
+// Sums run in the matrix unit's order, so results agree with the lane-per-problem kernel to
+// rounding, not bit for bit.
+typedef double v4f64_ __attribute__((ext_vector_type(4)));
+
+// One reverse sweep for the problem of this wave.  ASSUME_PD: branch-free LDL' solve of Quu that
+// only raises `bad` when a pivot is not positive; the kernel then repeats the sweep with the
+// pivoted-LU fallback (numpy.linalg.inv semantics, status bits).
+template <bool ASSUME_PD>
+__device__ __forceinline__ int ltv12x4_backward_sweep(const Params<double, 12, 4> &p, double *sh, int slot, int lane, bool &bad) {
+    constexpr int NX = 12, NU = 4;
+    const int c = lane & 15, g = lane >> 4;
+    const int T1 = p.N - 1;
+    const int tile = slot >> 6, ln = slot & 63;
+    const double *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
+    const double *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
+    const double *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
+    double *kp = tile_ptr(p.k, tile, T1 * NU, ln);
+    double *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    const bool isx = c < NX;
+    const int cu = isx ? 0 : c - NX;
+    // per-lane constants: weight of this lane's component of [x; u], diagonal positions of the tiles
+    const double lw = isx ? p.Q2[c * NX + c] : p.R2[cu * NU + cu];
+    bool dpos[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dpos[r] = (g + 4 * r == c);
+    auto load_xu = [&](int t) { return isx ? Xt[(size_t)(t * NX + c) * TILE] : Ut[(size_t)(t * NU + cu) * TILE]; };
+    auto load_xr = [&](int t) { return isx ? Rt[(size_t)(t * NX + c) * TILE] : 0.0; };
+    auto load_F = [&](int t, int kk) { // F[g + 4 kk][c] of step t
+        const int k = g + 4 * kk;
+        return isx ? p.ltvA[(size_t)t * NX * NX + k * NX + c] : p.ltvB[(size_t)t * NX * NU + k * NU + cu];
+    };
+    // terminal condition (ilqr.py:79-82): Vx = 2 Qf (x - xref), Vxx = 2 Qf
+    double vx = isx ? p.Qf2[c * NX + c] * (Xt[(size_t)(T1 * NX + c) * TILE] - Rt[(size_t)(T1 * NX + c) * TILE]) : 0.0;
+    double Vt[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) Vt[r] = (isx && dpos[r]) ? p.Qf2[c * NX + c] : 0.0;
+    int status = 0;
+    // the rows of the next PFL steps are in flight (a register ring; the loop is unrolled by PFL)
+    constexpr int PFL = 4;
+    double rxu[PFL], rxr[PFL], rF[PFL][3];
+#pragma unroll
+    for (int s = 0; s < PFL; ++s) {
+        const int ts = T1 - 1 - s > 0 ? T1 - 1 - s : 0;
+        rxu[s] = load_xu(ts);
+        rxr[s] = load_xr(ts);
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) rF[s][kk] = load_F(ts, kk);
+    }
+    for (int tb = T1 - 1; tb >= 0; tb -= PFL)
+#pragma unroll
+    for (int s = 0; s < PFL; ++s) {
+        const int t = tb - s;
+        if (t < 0) break;
+        const double xu_c = rxu[s], xr_c = rxr[s], F0 = rF[s][0], F1 = rF[s][1], F2 = rF[s][2];
+        const int tn = t - PFL > 0 ? t - PFL : 0;
+        rxu[s] = load_xu(tn);
+        rxr[s] = load_xr(tn);
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) rF[s][kk] = load_F(tn, kk);
+        // first-order terms: [Qx; Qu] = [lx; lu] + F' Vx (ilqr.py:93-94)
+        double part = F0 * __shfl(vx, g) + F1 * __shfl(vx, g + 4) + F2 * __shfl(vx, g + 8);
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        const double qv = fma_(lw, xu_c - xr_c, part);
+        // W = (Vxx + lm I) F
+        v4f64_ W = {0.0, 0.0, 0.0, 0.0};
+        W = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[0] + (dpos[0] && isx ? p.lm : 0.0), F0, W, 0, 0, 0);
+        W = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[1] + (dpos[1] && isx ? p.lm : 0.0), F1, W, 0, 0, 0);
+        W = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[2] + (dpos[2] && isx ? p.lm : 0.0), F2, W, 0, 0, 0);
+        // G = F' W in both layouts
+        v4f64_ TG = {0.0, 0.0, 0.0, 0.0}, DG = {0.0, 0.0, 0.0, 0.0};
+        TG = __builtin_amdgcn_mfma_f64_16x16x4f64(W[0], F0, TG, 0, 0, 0);
+        TG = __builtin_amdgcn_mfma_f64_16x16x4f64(W[1], F1, TG, 0, 0, 0);
+        TG = __builtin_amdgcn_mfma_f64_16x16x4f64(W[2], F2, TG, 0, 0, 0);
+        DG = __builtin_amdgcn_mfma_f64_16x16x4f64(F0, W[0], DG, 0, 0, 0);
+        DG = __builtin_amdgcn_mfma_f64_16x16x4f64(F1, W[1], DG, 0, 0, 0);
+        DG = __builtin_amdgcn_mfma_f64_16x16x4f64(F2, W[2], DG, 0, 0, 0);
+        // + lxx = 2Q, luu = 2R on the diagonal (ilqr.py:91-92)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) TG[r] += dpos[r] ? lw : 0.0;
+        const double qg = DG[3] + (dpos[3] ? lw : 0.0); // Qux[g][c] (c < 12), Quu[g][c - 12] (c >= 12)
+        __syncthreads();                                // the previous step has read sh
+        sh[g * 16 + c] = qg;
+        if (g == 0) sh[64 + c] = qv;
+        __syncthreads();
+        double Quu[NU][NU], rhs[NU][2], Qu[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) Quu[i][j] = sh[i * 16 + NX + j];
+            Qu[i] = sh[64 + NX + i];
+            rhs[i][0] = -Qu[i];
+            rhs[i][1] = -sh[i * 16 + c]; // -Qux[i][c]
+        }
+        status |= solve_quu<double, NU, 2, ASSUME_PD>(Quu, rhs, bad); // k = -Quu^-1 Qu, K[:, c] = -Quu^-1 Qux[:, c]
+        if (isx) Kp[(size_t)((t * NU + g) * NX + c) * TILE] = rhs[g == 0 ? 0 : g == 1 ? 1 : g == 2 ? 2 : 3][1];
+        if (!isx && g == 0) kp[(size_t)(t * NU + cu) * TILE] = rhs[cu][0];
+        const double kg = g == 0 ? rhs[0][1] : g == 1 ? rhs[1][1] : g == 2 ? rhs[2][1] : rhs[3][1]; // K[g][c]
+        // Vx = Qx + K' Qu ; Vxx = Qxx + K' Qux (ilqr.py:104-105)
+        double nvx = qv;
+#pragma unroll
+        for (int q = 0; q < NU; ++q) nvx = fma_(rhs[q][1], Qu[q], nvx);
+        vx = isx ? nvx : 0.0;
+        TG = __builtin_amdgcn_mfma_f64_16x16x4f64(isx ? qg : 0.0, isx ? kg : 0.0, TG, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Vt[r] = isx ? TG[r] : 0.0;
+    }
+    return status;
+}
+
+
+
+// REDO = false: every selected problem, branch-free solve; a problem whose Quu was not positive
+// definite somewhere is flagged in p.redo.  REDO = true (a second, normally idle launch): only the
+// flagged problems, with the pivoted-LU fallback.  Two kernels, so that the fallback's registers
+// do not cost the main kernel its occupancy.
+template <bool REDO> __global__ __launch_bounds__(64) void ltv12x4_backward_mfma_kernel(Params<double, 12, 4> p) {
+    __shared__ double sh[80];
+    const int lane = threadIdx.x;
+    const int nsl = slot_count(p);
+    // 64 consecutive workgroups of one XCD (workgroups are dealt to the 8 XCDs in turn) take the
+    // 64 problems of one tile, so that their 8-byte pieces of a row meet in that XCD's L2
+    const int bid = blockIdx.x, seq = bid >> 3;
+    const int slot = (((seq >> 6) << 3) + (bid & 7)) * 64 + (seq & 63);
+    if (slot >= nsl) return;
+    const int o = orig_of(p, slot);
+    if ((p.converged[o] == 0) == (p.select_converged != 0)) return;
+    if (REDO && p.redo[o] == 0) return;
+    bool bad = false;
+    const int status = ltv12x4_backward_sweep<!REDO>(p, sh, slot, lane, bad);
+    if (lane == 0) {
+        if (!REDO) p.redo[o] = bad ? 1 : 0;
+        if (status != 0 && p.status) p.status[o] |= status;
+    }
+}
+
 // ---------------------------------------------------------------- rollout step
 // u_new = (u_prev + alpha k) + K (x_new - x_prev), clamped (ilqr.py:56-61).
 template <typename T, class M, class P>
@@ -1229,6 +1388,119 @@ __global__ __launch_bounds__(64) void evaluate_listed_kernel(Params<T, M::NX, M:
         p.alpha_idx[o] = found ? best : -1;
         p.Jtry[o] = best_cost;
         p.slow_trig[o] = (p.slow_trig[o] & 6) | (pbad ? 1 : 0);
+    }
+}
+
+// ---------------------------------------------------------------- line search, n = 12, m = 4, fp64
+// One wave per problem on the fp64 matrix unit, all 16 step sizes at once: the candidates are
+// the columns of a 16 x 16 tile Z = [x; u] (rows 0..11 states, 12..15 inputs) in D-layout
+// (layouts: see ltv12x4_backward_mfma_kernel), so lane (c, g) carries candidate c and the
+// components g, g+4, g+8 of its state and input g.  A time step is X+ = [A_t | B_t] Z (four
+// calls) after the feedback K (X - x_prev) (three calls, result row g = input g in the lane that
+// holds that input).  Each lane accumulates its share of the candidate's cost; the four lanes of
+// a candidate are summed at the end.  Sums run in the matrix unit's order: costs and the accepted
+// step agree with the lane-per-candidate kernel to rounding, not bit for bit.
+//
+// A workgroup is 16 waves = 16 neighbouring problems of a tile, kept in step by a barrier every
+// few time steps: the 16 waves read their 8-byte pieces of the same 128-byte line within the same
+// step, so every line is fetched from HBM once (free-running waves drift apart over the horizon
+// and re-fetch the lines: 6x the traffic, measured).
+static __global__ __launch_bounds__(1024) void ltv12x4_evaluate_mfma_kernel(Params<double, 12, 4> p) {
+    constexpr int NX = 12, NU = 4;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int nsl = slot_count(p);
+    const int slot_raw = blockIdx.x * 16 + (threadIdx.x >> 6);
+    const int slot = slot_raw < nsl ? slot_raw : (nsl > 0 ? nsl - 1 : 0);
+    const int o = orig_of(p, slot);
+    const bool act = slot_raw < nsl && p.converged[o] == 0;
+    if (!__syncthreads_or(act)) return; // no wave of this workgroup has work
+    const int T1 = p.N - 1;
+    const int tile = slot >> 6, ln = slot & 63;
+    const double *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
+    const double *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
+    const double *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
+    const double *kp = tile_ptr(p.k, tile, T1 * NU, ln);
+    const double *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    const double Jcur = p.J[o];
+    const double alpha = pow2_neg<double>(c);
+    double qw[3], qfw[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        qw[r] = p.Q[(g + 4 * r) * NX + g + 4 * r];
+        qfw[r] = p.Qf[(g + 4 * r) * NX + g + 4 * r];
+    }
+    const double rw = p.R[g * NU + g], lo = p.lo[g], hi = p.hi[g];
+    struct Row {
+        double xp[3], xr[3], up, kf, Kop[3], Fop[4];
+    };
+    auto load_row = [&](int t, Row &r) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            r.xp[q] = Xt[(size_t)(t * NX + g + 4 * q) * TILE];
+            r.xr[q] = Rt[(size_t)(t * NX + g + 4 * q) * TILE];
+            r.Kop[q] = c < NU ? Kp[(size_t)((t * NU + c) * NX + g + 4 * q) * TILE] : 0.0;   // K[c][g + 4q]
+            r.Fop[q] = c < NX ? p.ltvA[(size_t)t * NX * NX + c * NX + g + 4 * q] : 0.0;      // A_t[c][g + 4q]
+        }
+        r.Fop[3] = c < NX ? p.ltvB[(size_t)t * NX * NU + c * NU + g] : 0.0;                   // B_t[c][g]
+        r.up = Ut[(size_t)(t * NU + g) * TILE];
+        r.kf = kp[(size_t)(t * NU + g) * TILE];
+    };
+    double z[4], cost = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) z[r] = Xt[(size_t)(g + 4 * r) * TILE];
+    z[3] = 0.0;
+    Row nxt;
+    load_row(0, nxt);
+    for (int t = 0; t < T1; ++t) {
+        if ((t & (LTV_SYNC_EVERY - 1)) == 0) __syncthreads();
+        if (!act) continue; // wave-uniform
+        const Row r = nxt;
+        load_row(t + 1 < T1 ? t + 1 : t, nxt);
+        double dx[3], e[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            dx[q] = z[q] - r.xp[q];
+            e[q] = z[q] - r.xr[q];
+        }
+        v4f64_ KD = {0.0, 0.0, 0.0, 0.0};
+        KD = __builtin_amdgcn_mfma_f64_16x16x4f64(r.Kop[0], dx[0], KD, 0, 0, 0);
+        KD = __builtin_amdgcn_mfma_f64_16x16x4f64(r.Kop[1], dx[1], KD, 0, 0, 0);
+        KD = __builtin_amdgcn_mfma_f64_16x16x4f64(r.Kop[2], dx[2], KD, 0, 0, 0);
+        // u_new = (u_prev + alpha k) + K (x_new - x_prev), clamped (ilqr.py:56-61)
+        double v = fma_(alpha, r.kf, r.up) + KD[0];
+        v = (lo > v) ? lo : v;
+        v = (hi < v) ? hi : v;
+        z[3] = v;
+        double stage = (qw[0] * e[0]) * e[0];
+        stage = fma_(qw[1] * e[1], e[1], stage);
+        stage = fma_(qw[2] * e[2], e[2], stage);
+        stage = fma_(rw * v, v, stage);
+        cost += stage;
+        v4f64_ Xn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Xn = __builtin_amdgcn_mfma_f64_16x16x4f64(r.Fop[q], z[q], Xn, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) z[q] = Xn[q];
+    }
+    {   // terminal term (ilqr.py:44-45)
+        double term = 0.0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const double e = z[q] - Rt[(size_t)(T1 * NX + g + 4 * q) * TILE];
+            term = fma_(qfw[q] * e, e, term);
+        }
+        cost += term;
+    }
+    cost += __shfl_xor(cost, 16);
+    cost += __shfl_xor(cost, 32);
+    // lowest step index whose cost improves strictly (ilqr.py:65; NaN never passes)
+    const unsigned long long win = __ballot(g == 0 && c < p.n_alphas && cost < Jcur);
+    const int best = win ? __ffsll((long long)win) - 1 : -1;
+    const double best_cost = __shfl(cost, best < 0 ? 0 : best);
+    if (act && lane == 0) {
+        p.alpha_idx[o] = best;
+        p.Jtry[o] = best < 0 ? 0.0 : best_cost;
+        p.slow_trig[o] = p.slow_trig[o] & 6;
     }
 }
 

@@ -563,6 +563,30 @@ def test_ltv12x4_matches_oracle(ilqr_cls, oracle, limits):
         assert np.array_equal(opt.alpha_history[b, :n][solid_o[:n]], r["hist_alpha"][b, :n][solid_o[:n]])
 
 
+def test_ltv12x4_indefinite_quu_uses_the_fallback_launch(ilqr_cls, oracle):
+    """The matrix-unit backward kernel of the n = 12 model solves Quu branch-free and flags the
+    problems in which a pivot was not positive; a second launch repeats those with the pivoted-LU
+    solve (numpy.linalg.inv semantics, ilqr.py:99) and sets the status bit.  Problems of the same
+    batch with a positive definite Quu must not be flagged."""
+    from ilqr_amd import _lib, problems, systems
+    N, B = 40, 6
+    A, Bm, Q, R = problems.ltv_system(N=N)
+    Rneg = R.copy()
+    Rneg[0, 0] = -abs(R[0, 0]) * 50.0                      # indefinite R -> indefinite Quu
+    s = systems.LTVSystem(A, Bm, dt=0.05)
+    s.set_cost(Q, Rneg)
+    p = problems.ltv_batch(B, N)
+    opt = ilqr_cls(s, p["target_states"], s.dt, history=True)
+    opt.inputs, opt.states, opt.maxIter = p["init_inputs"].copy(), p["init_states"].copy(), 1
+    opt()
+    assert np.all(opt.status & _lib.STATUS_NONPD)
+    d = oracle.make_desc(s, N, max_iter=1)
+    for b in (0, 5):
+        Ko, ko, rc = oracle.backward(d, np.ascontiguousarray(p["target_states"][b]), p["init_states"][b].copy(),
+                                     p["init_inputs"][b].copy())
+        assert nrm(opt.K[b], Ko) <= 1e-9 and nrm(opt.k[b][:, :, 0], ko) <= 1e-9
+
+
 def test_ltv12x4_fp32_mode(ilqr_cls, oracle):
     from ilqr_amd import problems
     N, B = 120, 8
