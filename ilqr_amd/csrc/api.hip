@@ -449,6 +449,23 @@ int ilqr_active_count(ilqr_handle *h, void *stream, int32_t *out) {
     return hip_rc(e);
 }
 
+int ilqr_shift(ilqr_handle *h, int32_t shift, const void *x0, void *stream) {
+    REQUIRE_BOUND(h);
+    const ilqr_desc &d = h->ctx.d;
+    if (shift < 0 || shift >= d.N) return ILQR_ERR_INVALID;
+    const ilqr_buffers &b = h->ctx.b;
+    const dim3 grid((d.B + TILE - 1) / TILE), block(64);
+    hipStream_t s = (hipStream_t)stream;
+    if (d.dtype == ILQR_F64)
+        hipLaunchKernelGGL(shift_kernel<double>, grid, block, 0, s, (double *)b.X, (double *)b.U, b.converged, b.iters,
+                           (const double *)x0, d.B, d.N, d.n, d.m, shift);
+    else
+        hipLaunchKernelGGL(shift_kernel<float>, grid, block, 0, s, (float *)b.X, (float *)b.U, b.converged, b.iters,
+                           (const float *)x0, d.B, d.N, d.n, d.m, shift);
+    h->ctx.reroll = false; // the shifted trajectory is a new initial guess
+    return hip_rc(hipGetLastError());
+}
+
 int ilqr_to_tiled(const void *aos, void *tiled, int32_t B, int32_t rows, int32_t elem_bytes, void *stream) {
     return relayout<true>(aos, tiled, B, rows, elem_bytes, stream);
 }

@@ -1758,6 +1758,37 @@ template <typename T> __global__ __launch_bounds__(64) void repack_move_kernel(R
     }
 }
 
+// ---------------------------------------------------------------- receding-horizon warm start
+// One lane per problem: the trajectory is moved `shift` steps towards the start (the last
+// state/input is repeated at the end), optionally the first state is replaced by a new initial
+// state given in the reference layout [B][n], and the problem is marked active again.  In place:
+// a row is read before the rows behind it are written.
+template <typename T>
+__global__ __launch_bounds__(64) void shift_kernel(T *X, T *U, int32_t *converged, int32_t *iters, const T *x0, int B, int N, int n,
+                                                   int m, int shift) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    const bool valid = b < B;
+    const int tile = blockIdx.x, ln = threadIdx.x;
+    T *Xt = tile_ptr(X, tile, N * n, ln);
+    T *Ut = tile_ptr(U, tile, (N - 1) * m, ln);
+    for (int t = 0; t < N; ++t) {
+        const int ts = t + shift < N ? t + shift : N - 1;
+        for (int i = 0; i < n; ++i) {
+            T v = Xt[(size_t)(ts * n + i) * TILE];
+            if (t == 0 && x0 && valid) v = x0[(size_t)b * n + i];
+            Xt[(size_t)(t * n + i) * TILE] = v;
+        }
+    }
+    for (int t = 0; t < N - 1; ++t) {
+        const int ts = t + shift < N - 1 ? t + shift : N - 2;
+        for (int i = 0; i < m; ++i) Ut[(size_t)(t * m + i) * TILE] = Ut[(size_t)(ts * m + i) * TILE];
+    }
+    if (valid) {
+        converged[b] = 0;
+        iters[b] = 0;
+    }
+}
+
 // ---------------------------------------------------------------- layout conversion
 // reference layout [B][rows] (one problem contiguous) <-> tiled device layout
 // [ceil(B/64)][rows][64].  One workgroup moves a 64-problem x 64-row patch through LDS so

@@ -165,6 +165,14 @@ int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream);
 /* number of problems with converged == 0; synchronises `stream` */
 int ilqr_active_count(ilqr_handle *h, void *stream, int32_t *out);
 
+/* Receding-horizon warm start, the device-resident form of re-assigning `.inputs` (and
+ * `.states[0]`) before calling the solver object again (ilqr_demo.py:47-49; ilqr.py:107-111
+ * continues from whatever the attributes hold): X[t] <- X[min(t+shift, N-1)],
+ * U[t] <- U[min(t+shift, N-2)] for every problem, then X[0] <- x0[b] if x0 (device pointer,
+ * reference layout [B][n], same element type) is not NULL; converged and iters are reset to 0.
+ * Follow it with ilqr_solve (or ilqr_initial_cost and the phase calls). */
+int ilqr_shift(ilqr_handle *h, int32_t shift, const void *x0, void *stream);
+
 /* layout helpers: reference layout [B][rows] (what numpy holds, e.g. states (B, N, n)
  * flattened) <-> tiled device layout [ceil(B/64)][rows][64]; elem_bytes 4 or 8; both
  * pointers are device pointers; padding lanes of the last tile are zero-filled */

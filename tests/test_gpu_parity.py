@@ -599,3 +599,42 @@ def test_ltv12x4_fp32_mode(ilqr_cls, oracle):
     r = oracle.solve_batch(d, p["target_states"], p["init_states"].copy(), p["init_inputs"].copy())
     assert np.abs(opt.cost_history[:, 0] - r["hist_cost"][:, 0]).max() <= 1e-4 * np.abs(r["hist_cost"][:, 0]).max()
     assert np.abs(opt.min_cost - r["min_cost"]).max() <= 2e-3 * np.abs(r["min_cost"]).max()
+
+
+# --------------------------------------------------------------------------- receding horizon
+def test_receding_horizon_driver_equals_manual_warm_starts(ilqr_cls):
+    """ilqr_amd.mpc.RecedingHorizon keeps everything on the device: shifting the previous
+    solution there, installing prefetched targets and new initial states, and solving again must
+    give bit for bit what a fresh solver object gives when the same warm start is assigned through
+    its attributes (the reference's way, ilqr_demo.py:47-49)."""
+    from ilqr_amd import problems
+    from ilqr_amd.mpc import RecedingHorizon
+    B, N = 70, 60
+    car = demo_car_system()
+    p = problems.car_batch(B, N)
+    opt = ilqr_cls(car, p["target_states"], car.dt)
+    opt.inputs, opt.states = p["init_inputs"].copy(), p["init_states"].copy()
+    mpc = RecedingHorizon(opt)
+    u0 = mpc.step(first=True)
+    sol = mpc.solution()
+    ref = ilqr_cls(car, p["target_states"], car.dt)
+    ref.inputs, ref.states = p["init_inputs"].copy(), p["init_states"].copy()
+    ref()
+    assert np.array_equal(sol.inputs, ref.inputs) and np.array_equal(u0, ref.inputs[:, 0])
+    prev_x, prev_u, tg = ref.states.copy(), ref.inputs.copy(), p["target_states"]
+    for k, shift in enumerate((1, 3, 1)):
+        tg = np.concatenate([tg[:, shift:], np.repeat(tg[:, -1:], shift, axis=1)], axis=1) + 0.01 * (k + 1)
+        x0 = prev_x[:, shift] + 0.02                      # "measured" state: the plan, disturbed
+        mpc.prefetch_targets(tg)
+        u0 = mpc.step(shift=shift, x0=x0)
+        sol = mpc.solution()
+        xs = np.concatenate([prev_x[:, shift:], np.repeat(prev_x[:, -1:], shift, axis=1)], axis=1)
+        xs[:, 0] = x0
+        us = np.concatenate([prev_u[:, shift:], np.repeat(prev_u[:, -1:], shift, axis=1)], axis=1)
+        man = ilqr_cls(car, tg, car.dt)
+        man.inputs, man.states = us.copy(), xs.copy()
+        man()
+        for key in ("states", "inputs", "min_cost", "iterations", "converge"):
+            assert np.array_equal(getattr(sol, key), getattr(man, key)), (k, key)
+        assert np.array_equal(u0, man.inputs[:, 0])
+        prev_x, prev_u = man.states.copy(), man.inputs.copy()
