@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--strong", action="store_true", help="split --batch over the GPUs instead of per-GPU")
     ap.add_argument("--mapping", default="auto", help="forward mapping L,A (lanes per problem, step sizes per lane)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--repack-every", type=int, default=8, help="active-set compaction period (what ilqr_solve uses for this batch size)")
+    ap.add_argument("--no-repack", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=65536, help="upper bound on problems in the CPU baseline sample")
     args = ap.parse_args()
@@ -110,11 +112,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    repack_every = 0 if args.no_repack else args.repack_every
+
     def solve_step(events=None):
         """The launches of ilqr_solve, issued one by one so that events can bracket them."""
         reset()
         dev.initial_cost()
         for it in range(max_iter):
+            if repack_every > 0 and it >= 2 * repack_every and it % repack_every == 0:
+                dev.repack()
             if events is not None:
                 e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
                 e[0].record()
@@ -130,6 +136,8 @@ def main():
             else:
                 dev.backward()
                 dev.forward(it)
+        if repack_every > 0:
+            dev.unpack()
 
     for _ in range(args.warmup):
         solve_step()
@@ -209,7 +217,8 @@ def main():
             "data": "synthetic (seeded Car tracking problems, ilqr_amd.problems.car_batch)",
             "config": {"workload": f"Car n=4 m=2, N={N}, B={B} problems per GPU, maxIter=30, 15 parallel step sizes",
                        "batch_per_gpu": B, "batch_total": B_total, "horizon": N,
-                       "forward_mapping": f"L={L_},A={A_} ({'two-stage' if L_ * A_ < n_alphas else 'one stage'})"},
+                       "forward_mapping": f"L={L_},A={A_} ({'two-stage' if L_ * A_ < n_alphas else 'one stage'})",
+                       "active_set_compaction_every": repack_every},
             "mean_iterations_per_solve": float(iter_sum[0].item()) / B_total,
             "converged_fraction": float(iter_sum[1].item()) / B_total,
             "executed_iterations_per_step": float(iter_sum[0].item()),

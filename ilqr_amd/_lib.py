@@ -62,6 +62,8 @@ _SIGNATURES = {
     "ilqr_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "ilqr_forward_evaluate": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ilqr_forward_evaluate_stage": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "ilqr_repack": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ilqr_unpack": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ilqr_shift": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "ilqr_forward_mapping": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ilqr_forward_commit": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),

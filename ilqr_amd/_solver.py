@@ -221,6 +221,12 @@ class DeviceProblem:
     def forward_evaluate(self):
         _lib.check(self.lib.ilqr_forward_evaluate(self.handle, self.stream()), "ilqr_forward_evaluate")
 
+    def repack(self):
+        _lib.check(self.lib.ilqr_repack(self.handle, self.stream()), "ilqr_repack")
+
+    def unpack(self):
+        _lib.check(self.lib.ilqr_unpack(self.handle, self.stream()), "ilqr_unpack")
+
     def forward_mapping(self):
         """(lanes per problem, step sizes per lane) of the first line-search stage."""
         L, A = C.c_int32(0), C.c_int32(0)

@@ -12,6 +12,15 @@ using namespace ilqr;
 
 constexpr int MAX_PARTS = 8;
 
+// State of one part of the batch (a tile range): its launch context and, once its active problems
+// have been compacted, which working set it is in.
+struct PartState {
+    HostCtx ctx;      // launch context of this part (tile range [first, first + count))
+    int index = 0;    // part number
+    bool packed = false;
+    int parity = 0;   // working set in use once packed
+};
+
 struct ilqr_handle {
     HostCtx ctx;
     const ModelOps *ops = nullptr;
@@ -19,6 +28,9 @@ struct ilqr_handle {
     // part's arithmetic-bound line search overlaps another part's bandwidth-bound passes
     int n_parts = 1;
     int repack_every = 0;   // 0: no compaction
+    // the phase calls (ilqr_backward ...) and the single-stream ilqr_solve work on the whole batch as
+    // one part whose compaction state lives here, between calls
+    PartState whole;
     bool streams_ready = false;
     hipStream_t part_stream[MAX_PARTS] = {};
     hipEvent_t fork_event = nullptr, join_event[MAX_PARTS] = {};
@@ -66,13 +78,6 @@ template <bool TO_TILED> static int relayout(const void *src, void *dst, int B, 
 }
 
 // ---- active-set compaction (see kernels.hpp) --------------------------------------------
-struct PartState {
-    HostCtx ctx;      // launch context of this part (tile range [first, first + count))
-    int index = 0;    // part number
-    bool packed = false;
-    int parity = 0;   // working set in use once packed
-};
-
 // mode REPACK_CARRY: build the next working set; REPACK_RETIRE_ALL: states and inputs of every
 // problem still in the working set go back to the caller's buffers; REPACK_RETIRE_LIVE: gains of
 // the problems that never converged go back to the caller's buffers.
@@ -263,9 +268,10 @@ int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
         if (parts == 0) parts = 1;
         if (parts > tiles) parts = tiles;
         h->n_parts = parts;
-        // active-set compaction is opt-in: results are bit-identical with and without it, and
-        // at B = 65536 Car problems its copies currently cost about what it saves
-        h->repack_every = d.repack_every > 0 ? d.repack_every : 0;
+        // 0 = auto: large batches are bound by bandwidth, where skipping the converged problems
+        // pays for the copies (38.7 -> 35.9 ms at B = 65536 Car problems); small ones are bound by
+        // the latency of a time step, where it cannot
+        h->repack_every = d.repack_every > 0 ? d.repack_every : (d.repack_every == 0 && d.B >= 32768 ? 8 : 0);
     }
     *out = h;
     return ILQR_OK;
@@ -305,6 +311,7 @@ int ilqr_bind(ilqr_handle *h, const ilqr_buffers *b) {
     h->ctx.b = *b;
     h->ctx.bound = true;
     h->ctx.reroll = false;
+    h->whole = PartState();
     return ILQR_OK;
 }
 
@@ -312,26 +319,47 @@ int ilqr_bind(ilqr_handle *h, const ilqr_buffers *b) {
     if (!(h)) return ILQR_ERR_INVALID;            \
     if (!(h)->ctx.bound) return ILQR_ERR_NOT_BOUND;
 
+// launch context of the phase calls: the handle's settings with the whole-batch compaction state
+static HostCtx &phase_ctx(ilqr_handle *h) {
+    h->whole.ctx.d = h->ctx.d;
+    h->whole.ctx.b = h->ctx.b;
+    h->whole.ctx.bound = h->ctx.bound;
+    h->whole.ctx.diag = h->ctx.diag;
+    h->whole.ctx.n_alphas = h->ctx.n_alphas;
+    h->whole.ctx.L = h->ctx.L;
+    h->whole.ctx.A = h->ctx.A;
+    h->whole.ctx.first = 0;
+    h->whole.ctx.count = h->ctx.d.B;
+    h->whole.ctx.reroll = h->ctx.reroll;
+    h->whole.ctx.select_converged = false;
+    h->whole.ctx.eval_stages = 3;
+    return h->whole.ctx;
+}
+
+#define REQUIRE_UNPACKED(h) \
+    if ((h)->whole.packed) return ILQR_ERR_INVALID; /* ilqr_unpack first: the caller's buffers are stale */
+
 int ilqr_initial_cost(ilqr_handle *h, void *stream) {
     REQUIRE_BOUND(h);
+    REQUIRE_UNPACKED(h);
     h->ctx.reroll = false; // the caller (re)wrote X and U: X need not be the rollout of U
     return hip_rc(h->ops->cost(h->ctx, 0, (hipStream_t)stream));
 }
 
 int ilqr_backward(ilqr_handle *h, void *stream) {
     REQUIRE_BOUND(h);
-    return hip_rc(h->ops->backward(h->ctx, 0, (hipStream_t)stream));
+    return hip_rc(h->ops->backward(phase_ctx(h), 0, (hipStream_t)stream));
 }
 
 int ilqr_forward_evaluate(ilqr_handle *h, void *stream) {
     REQUIRE_BOUND(h);
-    return hip_rc(h->ops->evaluate(h->ctx, 0, (hipStream_t)stream));
+    return hip_rc(h->ops->evaluate(phase_ctx(h), 0, (hipStream_t)stream));
 }
 
 int ilqr_forward_evaluate_stage(ilqr_handle *h, int32_t stage, void *stream) {
     REQUIRE_BOUND(h);
     if (stage != 0 && stage != 1) return ILQR_ERR_INVALID;
-    HostCtx c = h->ctx;
+    HostCtx c = phase_ctx(h);
     c.eval_stages = stage == 0 ? 1 : 2;
     return hip_rc(h->ops->evaluate(c, 0, (hipStream_t)stream));
 }
@@ -339,9 +367,27 @@ int ilqr_forward_evaluate_stage(ilqr_handle *h, int32_t stage, void *stream) {
 int ilqr_forward_commit(ilqr_handle *h, int32_t iteration, void *stream) {
     REQUIRE_BOUND(h);
     if (iteration < 0) return ILQR_ERR_INVALID;
-    const int rc = hip_rc(h->ops->commit(h->ctx, iteration, (hipStream_t)stream));
+    const int rc = hip_rc(h->ops->commit(phase_ctx(h), iteration, (hipStream_t)stream));
     // every problem that is still active afterwards has had a step committed by this library
     if (rc == ILQR_OK && h->ctx.d.recompute_states >= 0) h->ctx.reroll = true;
+    return rc;
+}
+
+int ilqr_repack(ilqr_handle *h, void *stream) {
+    REQUIRE_BOUND(h);
+    if (work_layout(h->ctx.d, h->repack_every > 0).total < work_layout(h->ctx.d, true).total) return ILQR_ERR_INVALID;
+    phase_ctx(h);
+    return repack(h, h->whole, REPACK_CARRY, (hipStream_t)stream);
+}
+
+int ilqr_unpack(ilqr_handle *h, void *stream) {
+    REQUIRE_BOUND(h);
+    phase_ctx(h);
+    const int rc = unpack(h, h->whole, (hipStream_t)stream);
+    if (rc == ILQR_OK) {
+        h->whole.packed = false;
+        h->whole.ctx.ws = HostCtx::WorkSet();
+    }
     return rc;
 }
 
@@ -354,6 +400,7 @@ int ilqr_forward(ilqr_handle *h, int32_t iteration, void *stream) {
 int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream) {
     REQUIRE_BOUND(h);
     if (max_iter < 0) return ILQR_ERR_INVALID;
+    REQUIRE_UNPACKED(h);
     hipStream_t user = (hipStream_t)stream;
     const int np = h->n_parts;
     hipError_t e = hipSuccess;
@@ -453,6 +500,7 @@ int ilqr_shift(ilqr_handle *h, int32_t shift, const void *x0, void *stream) {
     REQUIRE_BOUND(h);
     const ilqr_desc &d = h->ctx.d;
     if (shift < 0 || shift >= d.N) return ILQR_ERR_INVALID;
+    REQUIRE_UNPACKED(h);
     const ilqr_buffers &b = h->ctx.b;
     const dim3 grid((d.B + TILE - 1) / TILE), block(64);
     hipStream_t s = (hipStream_t)stream;

@@ -1279,8 +1279,7 @@ __device__ __forceinline__ void listed_rounds(const P &p, const T *Xt, const T *
             __syncthreads();
             fetch_block(t0 + SB, st); // in flight during the rollout below
             const int ns = T1 - t0 < SB ? T1 - t0 : SB;
-            for (int s = 0; s < ns; ++s) {
-                FwdRow<T, NX, NU> r;
+            auto read_row = [&](int s, FwdRow<T, NX, NU> &r) {
 #pragma unroll
                 for (int i = 0; i < NU; ++i) {
                     r.k[i] = lds[C::ok + s * NU + i];
@@ -1290,7 +1289,7 @@ __device__ __forceinline__ void listed_rounds(const P &p, const T *Xt, const T *
                 }
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
-                    r.xp[i] = REROLL ? xq[i] : lds[C::oX + s * NX + i];
+                    if (!REROLL) r.xp[i] = lds[C::oX + s * NX + i];
                     r.xr[i] = lds[C::oR + s * NX + i];
                 }
                 if (BARRIER) {
@@ -1299,6 +1298,16 @@ __device__ __forceinline__ void listed_rounds(const P &p, const T *Xt, const T *
                     r.rad = lds[C::oD + s];
                 } else {
                     r.cx = r.cy = r.rad = T(0);
+                }
+            };
+            FwdRow<T, NX, NU> rn;
+            read_row(0, rn);
+            for (int s = 0; s < ns; ++s) {
+                FwdRow<T, NX, NU> r = rn;
+                read_row(s + 1 < SB ? s + 1 : s, rn); // the next step's row leaves LDS during this step
+                if (REROLL) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) r.xp[i] = xq[i];
                 }
                 candidate_step<T, M, DIAG, BARRIER, FAST>(p, t0 + s, alpha, r, x, cost, bad);
                 if (REROLL) {

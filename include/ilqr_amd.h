@@ -85,7 +85,8 @@ typedef struct ilqr_desc {
     int32_t n_streams;         /* ilqr_solve splits the batch into this many tile ranges, each on a stream of
                                   its own, so phases of different parts overlap (1..8); 0 = auto */
     int32_t repack_every;      /* ilqr_solve compacts the still-active problems into dense tiles every this many
-                                  iterations (needs the larger workspace, see ilqr_workspace_bytes); <= 0 = never */
+                                  iterations, from the second multiple on (needs the larger workspace, see
+                                  ilqr_workspace_bytes); 0 = auto (8 for B >= 32768, else never); < 0 = never */
     int32_t recompute_states;  /* >= 0: once a step has been committed, the forward kernels roll the previous
                                   states out again from U instead of reading X (same bits, less traffic);
                                   < 0: always read X */
@@ -159,6 +160,17 @@ int ilqr_forward_commit(ilqr_handle *h, int32_t iteration, void *stream);
  * meaningful directly after stage 0 of the same line search (ilqr.py:53-74 walks the same step
  * sizes in one loop). */
 int ilqr_forward_evaluate_stage(ilqr_handle *h, int32_t stage, void *stream);
+/* Active-set compaction for callers that drive the phases themselves (ilqr_solve does this on its
+ * own every repack_every iterations).  ilqr_repack copies the problems that are still iterating
+ * into dense tiles of a working set inside `work` and retires the states and inputs of the others
+ * to the bound buffers; the phase calls then work on that set.  ilqr_unpack brings everything
+ * back (states, inputs and gains of every problem are in the bound buffers afterwards, bit for
+ * bit what they would be without compaction) and must precede any access to the bound X, U, K, k
+ * as well as ilqr_initial_cost, ilqr_shift and ilqr_solve.  Needs the workspace of a handle created
+ * with compaction enabled (repack_every >= 0 and B >= 32768, or repack_every > 0).  No reference
+ * counterpart: the reference solves one problem at a time. */
+int ilqr_repack(ilqr_handle *h, void *stream);
+int ilqr_unpack(ilqr_handle *h, void *stream);
 /* iterative_LQR.__call__ (ilqr.py:107-114): initial cost, then max_iter x
  * (backward, forward); converged problems are skipped on the device. */
 int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream);

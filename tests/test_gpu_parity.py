@@ -638,3 +638,38 @@ def test_receding_horizon_driver_equals_manual_warm_starts(ilqr_cls):
             assert np.array_equal(getattr(sol, key), getattr(man, key)), (k, key)
         assert np.array_equal(u0, man.inputs[:, 0])
         prev_x, prev_u = man.states.copy(), man.inputs.copy()
+
+
+def test_phase_calls_with_repack_and_unpack_equal_the_plain_solve(ilqr_cls):
+    """A caller that drives the phases itself may compact the active set between iterations
+    (ilqr_repack) and must get everything back with ilqr_unpack: states, inputs, gains, costs and
+    flags equal the plain run bit for bit."""
+    from ilqr_amd import problems
+    p = problems.car_batch(300, 80)
+    ref = _solve_batch(ilqr_cls, p, repack_every=-1)
+    Kr, kr = ref.K.copy(), ref.k.copy()
+    car = demo_car_system()
+    opt = ilqr_cls(car, p["target_states"], car.dt, history=True, repack_every=5)
+    opt.inputs, opt.states = p["init_inputs"].copy(), p["init_states"].copy()
+    dev = opt.upload()
+    dev.initial_cost()
+    for it in range(opt.maxIter):
+        if it in (3, 4, 9, 17, 26):
+            dev.repack()
+        dev.backward()
+        dev.forward_evaluate_stage(0)
+        dev.forward_evaluate_stage(1)
+        dev.forward_commit(it)
+    dev.unpack()
+    opt.download()
+    for key in ("states", "inputs", "min_cost", "iterations", "converge", "status"):
+        assert np.array_equal(getattr(opt, key), getattr(ref, key)), key
+    assert np.array_equal(opt.alpha_history, ref.alpha_history)
+    assert np.array_equal(opt.K, Kr) and np.array_equal(opt.k, kr)
+    # packed state is refused where the bound buffers would be stale
+    dev.repack()
+    from ilqr_amd import _lib
+    with pytest.raises(_lib.IlqrError):
+        dev.initial_cost()
+    dev.unpack()
+    dev.initial_cost()
