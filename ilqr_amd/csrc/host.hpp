@@ -268,23 +268,33 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
         if (!two || !(c.eval_stages & 2)) return hipSuccess;
         // the length of the list is only known on the device: the grid covers the worst case and
         // the waves beyond the list leave at once
-        constexpr int L2 = M::NX > 8 ? 16 : 8;
-        const int ppw = 64 / L2;
-        const int blocks = (int)(((long)c.count + ppw - 1) / ppw); // one wave per workgroup
-        hipLaunchKernelGGL((evaluate_listed_kernel<T, M, DIAG, BARRIER, L2, REROLL>), dim3(blocks), dim3(64), 0, s, p, first_end, c.n_alphas);
+        // one round of stage two should cover all remaining candidates: 8 lanes per listed problem
+        // if at most 8 remain, else 16
+        if (M::NX > 8 || c.n_alphas - first_end > 8) {
+            const int blocks = (int)(((long)c.count + 3) / 4); // one wave per workgroup, 4 problems per wave
+            hipLaunchKernelGGL((evaluate_listed_kernel<T, M, DIAG, BARRIER, 16, REROLL>), dim3(blocks), dim3(64), 0, s, p, first_end, c.n_alphas);
+        } else if constexpr (M::NX <= 8) {
+            const int blocks = (int)(((long)c.count + 7) / 8);
+            hipLaunchKernelGGL((evaluate_listed_kernel<T, M, DIAG, BARRIER, 8, REROLL>), dim3(blocks), dim3(64), 0, s, p, first_end, c.n_alphas);
+        }
         return hipGetLastError();
     }
     template <bool BARRIER, int L, int A, bool REROLL> static hipError_t eval_stage_one(const HostCtx &c, hipStream_t s, int first_end) {
         hipError_t e;
-        if constexpr (M::NX <= 8 && L == 1 && A == 8) {
+        if constexpr (M::NX <= 8 && L == 1 && (A == 8 || A == 6)) {
             // Compacted working set: the number of slots shrinks during the solve and is only
             // known on the device.  With fewer than one tile per SIMD, one lane per problem leaves
-            // SIMDs idle while each wave still walks its 8 candidates in sequence, so mappings with
-            // more lanes per problem take over; all are launched and each looks at the count.
+            // SIMDs idle while each wave still walks its candidates in sequence, so mappings with
+            // more lanes per problem (and the same number of candidates, which stage two relies
+            // on) take over; all are launched and each looks at the count.
             if (c.ws.slot2orig != nullptr) {
-                e = eval_first<BARRIER, 1, 8, REROLL>(c, s, first_end, 40960, 0x7fffffff);
-                if (e == hipSuccess) e = eval_first<BARRIER, 2, 4, REROLL>(c, s, first_end, 20480, 40960);
-                if (e == hipSuccess) e = eval_first<BARRIER, 4, 2, REROLL>(c, s, first_end, -1, 20480);
+                e = eval_first<BARRIER, 1, A, REROLL>(c, s, first_end, 40960, 0x7fffffff);
+                if constexpr (A == 8) {
+                    if (e == hipSuccess) e = eval_first<BARRIER, 2, 4, REROLL>(c, s, first_end, 20480, 40960);
+                    if (e == hipSuccess) e = eval_first<BARRIER, 4, 2, REROLL>(c, s, first_end, -1, 20480);
+                } else {
+                    if (e == hipSuccess) e = eval_first<BARRIER, 2, 3, REROLL>(c, s, first_end, -1, 40960);
+                }
             } else {
                 e = eval_first<BARRIER, L, A, REROLL>(c, s, first_end, -1, 0x7fffffff);
             }
@@ -313,6 +323,8 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
             case 402: return eval_la<BARRIER, 4, 2>(c, s);
             case 204: return eval_la<BARRIER, 2, 4>(c, s);
             case 108: return eval_la<BARRIER, 1, 8>(c, s);
+            case 106: return eval_la<BARRIER, 1, 6>(c, s);
+            case 203: return eval_la<BARRIER, 2, 3>(c, s);
             default: return hipErrorInvalidValue;
             }
         }

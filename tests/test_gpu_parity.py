@@ -171,7 +171,7 @@ def test_all_forward_mappings_are_bit_identical(ilqr_cls):
     from ilqr_amd import problems
     p = problems.car_batch(200, 120)
     ref = _solve_batch(ilqr_cls, p, lanes_per_problem=16, alphas_per_lane=1)
-    for L, A in ((8, 2), (4, 4), (2, 8), (8, 1), (4, 2), (2, 4), (1, 8)):
+    for L, A in ((8, 2), (4, 4), (2, 8), (8, 1), (4, 2), (2, 4), (1, 8), (1, 6), (2, 3)):
         o = _solve_batch(ilqr_cls, p, lanes_per_problem=L, alphas_per_lane=A)
         assert np.array_equal(o.min_cost, ref.min_cost), (L, A)
         assert np.array_equal(o.iterations, ref.iterations)
@@ -227,7 +227,7 @@ def test_compaction_and_streams_do_not_change_a_bit(ilqr_cls):
     ref = _solve_batch(ilqr_cls, p, repack_every=-1, n_streams=1)
     Kr, kr = ref.K.copy(), ref.k.copy()
     assert ref.converge.any() and not ref.converge.all()     # both kinds of problems present
-    for every, ns, L, A in ((1, 1, 0, 0), (3, 1, 0, 0), (4, 2, 0, 0), (2, 3, 2, 4), (7, 1, 0, 0), (-1, 3, 1, 8), (3, 2, 8, 1)):
+    for every, ns, L, A in ((1, 1, 0, 0), (3, 1, 0, 0), (4, 2, 0, 0), (2, 3, 2, 4), (7, 1, 0, 0), (-1, 3, 1, 8), (3, 2, 8, 1), (4, 1, 1, 6)):
         o = _solve_batch(ilqr_cls, p, repack_every=every, n_streams=ns, lanes_per_problem=L, alphas_per_lane=A)
         for key in ("states", "inputs", "min_cost", "iterations", "converge", "status"):
             assert np.array_equal(getattr(o, key), getattr(ref, key)), (every, ns, key)
