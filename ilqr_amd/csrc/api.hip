@@ -148,6 +148,8 @@ static hipError_t repack_launch(ilqr_handle *h, PartState &ps, int mode, hipStre
     a.B = ps.ctx.count;
     a.first = ps.ctx.first;
     a.mode = mode;
+    a.carried = (int32_t *)(work + wl.carried);
+    a.first_repack = pk ? 0 : 1;
     if (a.narr > 0) hipLaunchKernelGGL((repack_move_kernel<T>), dim3(ntiles, chunks), dim3(64), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !carry) return e;

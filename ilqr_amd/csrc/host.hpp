@@ -40,7 +40,7 @@ struct HostCtx {
 // exist; the rest only with active-set compaction.
 struct WorkLayout {
     size_t jtry = 0, slow = 0, counters = 0, list = 0, list_count = 0, trash = 0, redo = 0;
-    size_t map[2] = {0, 0}, tile_count = 0, tile_offset = 0, nslots = 0;
+    size_t map[2] = {0, 0}, tile_count = 0, tile_offset = 0, nslots = 0, carried = 0;
     size_t set[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}; // X, U, Xref, centers, radius of the two working sets
     size_t Kw = 0, kw = 0;
     size_t total = 0;
@@ -71,6 +71,7 @@ static inline WorkLayout work_layout(const ilqr_desc &d, bool compaction) {
         w.tile_count = take(tiles * 4);
         w.tile_offset = take(tiles * 4);
         w.nslots = take(256);
+        w.carried = take((size_t)d.B * 4);
         for (int q = 0; q < 2; ++q) {
             w.set[q][0] = take(Bp * N * n * e);
             w.set[q][1] = take(Bp * T1 * m * e);
@@ -152,6 +153,7 @@ template <typename T, int NX, int NU> static Params<T, NX, NU> make_params(const
     p.N = d.N;
     p.n_alphas = c.n_alphas;
     p.select_converged = c.select_converged ? 1 : 0;
+    p.carried = c.select_converged ? (const int32_t *)((char *)b.work + work_layout(d, true).carried) : nullptr;
     p.slots_lo = -1;
     p.slots_hi = 0x7fffffff;
     p.dt = (T)d.dt;

@@ -126,6 +126,7 @@ template <typename T, int NX, int NU> struct Params {
     // before stage one, the stage-one kernel appends)
     int32_t *list;
     int32_t *list_count;
+    const int32_t *carried; // per problem: was ever copied into a working set (select_converged only)
     int32_t *redo; // per problem: the backward pass must be repeated with the pivoted-LU solve (n = 12 model)
     T *trash; // 64 values per tile: where lanes that must not change their trajectory store (commit, REROLL)
     const T *centers, *radius;
@@ -770,7 +771,8 @@ __global__ __launch_bounds__(64) void backward_kernel(Params<T, M::NX, M::NU> p)
     const bool valid = b0 < nsl;
     const int o = orig_of(p, valid ? b0 : nsl - 1);
     // normally the problems still iterating; at the end of a solve with compaction, the converged ones
-    const bool active = valid && (p.converged[o] == 0) != (p.select_converged != 0);
+    // whose gains were computed inside a working set
+    const bool active = valid && (p.select_converged ? (p.converged[o] != 0 && p.carried[o] != 0) : p.converged[o] == 0);
     if (__ballot(active) == 0ull) return;
     const int T1 = p.N - 1;
     constexpr bool BARRIER_ = (CONSTR & 2) != 0;
@@ -937,7 +939,7 @@ template <bool REDO> __global__ __launch_bounds__(64) void ltv12x4_backward_mfma
     const int slot = (((seq >> 6) << 3) + (bid & 7)) * 64 + (seq & 63);
     if (slot >= nsl) return;
     const int o = orig_of(p, slot);
-    if ((p.converged[o] == 0) == (p.select_converged != 0)) return;
+    if (p.select_converged ? (p.converged[o] == 0 || p.carried[o] == 0) : p.converged[o] != 0) return;
     if (REDO && p.redo[o] == 0) return;
     bool bad = false;
     const int status = ltv12x4_backward_sweep<!REDO>(p, sh, slot, lane, bad);
@@ -1727,6 +1729,8 @@ template <typename T> struct RepackArgs {
     int B;                        // problems of this part (slots before the first repack)
     int first;                    // global index of the part's first problem
     int mode;                     // REPACK_*
+    int32_t *carried;             // per problem: has been copied into a working set (its gains are not in the caller's buffers)
+    int first_repack;             // the current arrays are the caller's buffers: define `carried` for every problem
 };
 
 // blockIdx.x: tile of the current working set; blockIdx.y: a chunk of REPACK_CHUNK rows of one of
@@ -1745,6 +1749,7 @@ template <typename T> __global__ __launch_bounds__(64) void repack_move_kernel(R
     const unsigned long long m = __ballot(act);
     const int ns = act ? a.tile_offset[tile] + (int)__popcll(m & ((1ull << lane) - 1ull)) : 0;
     if (act && blockIdx.y == 0) a.slot2orig_new[ns] = o;
+    if (valid && blockIdx.y == 0 && a.mode == REPACK_CARRY && (act || a.first_repack)) a.carried[o] = act ? 1 : 0;
     int q = 0;
     while (q + 1 < a.narr && (int)blockIdx.y >= a.arr[q + 1].chunk0) ++q;
     const RepackArray<T> r = a.arr[q];
