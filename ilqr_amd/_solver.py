@@ -41,7 +41,8 @@ class DeviceProblem:
     def __init__(self, system, B, N, dtype, device, *, max_iter, lm_parameter, alpha_floor,
                  constraint_mode=_lib.CONSTR_NONE, input_limit_lambda=1e-4, barrier_mu=0.0,
                  barrier_delta=0.1, vel_bounds=(0.0, 0.0), lanes_per_problem=0, alphas_per_lane=0,
-                 history=False, solver_limits=False, n_streams=0, repack_every=0, recompute_states=0):
+                 history=False, solver_limits=False, n_streams=0, repack_every=0, recompute_states=0,
+                 overlap_stages=0):
         torch = _torch()
         if not torch.cuda.is_available():
             raise _lib.IlqrError("no GPU visible: the batched iLQR solve runs on the HIP device only")
@@ -68,6 +69,7 @@ class DeviceProblem:
         d.n_streams = int(n_streams)
         d.repack_every = int(repack_every)
         d.recompute_states = int(recompute_states)
+        d.overlap_stages = int(overlap_stages)
         d.dt = float(system.dt)
         d.lm_parameter = float(lm_parameter)
         d.alpha_floor = float(alpha_floor)
@@ -263,7 +265,8 @@ class BatchedSolverBase:
     _constraint_mode = _lib.CONSTR_NONE
 
     def __init__(self, sys, target_states, dt, device=None, dtype=np.float64, history=False,
-                 lanes_per_problem=0, alphas_per_lane=0, n_streams=0, repack_every=0, recompute_states=0):
+                 lanes_per_problem=0, alphas_per_lane=0, n_streams=0, repack_every=0, recompute_states=0,
+                 overlap_stages=0):
         if not isinstance(sys, System) and not hasattr(sys, "state_size"):
             raise TypeError("sys must provide the systems.System interface")
         self.target_states = target_states
@@ -302,6 +305,7 @@ class BatchedSolverBase:
         self._n_streams = int(n_streams)
         self._repack_every = int(repack_every)
         self._recompute_states = int(recompute_states)
+        self._overlap_stages = int(overlap_stages)
         self._dev = None
         self._k_cache = self._K_cache = None
         self.cost_history = None
@@ -337,7 +341,8 @@ class BatchedSolverBase:
                 constraint_mode=self._constraint_mode, history=self._history,
                 lanes_per_problem=self._mapping[0], alphas_per_lane=self._mapping[1],
                 n_streams=self._n_streams, repack_every=self._repack_every,
-                recompute_states=self._recompute_states, **self._extra_desc())
+                recompute_states=self._recompute_states, overlap_stages=self._overlap_stages,
+                **self._extra_desc())
             self._dev_key = key
         return self._dev
 

@@ -31,6 +31,10 @@ struct ilqr_handle {
     // the phase calls (ilqr_backward ...) and the single-stream ilqr_solve work on the whole batch as
     // one part whose compaction state lives here, between calls
     PartState whole;
+    // stream and events of the second line-search stage when it runs beside the commit
+    bool overlap = false;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool streams_ready = false;
     hipStream_t part_stream[MAX_PARTS] = {};
     hipEvent_t fork_event = nullptr, join_event[MAX_PARTS] = {};
@@ -278,6 +282,9 @@ int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
         // the latency of a time step, where it cannot
         h->repack_every = d.repack_every > 0 ? d.repack_every : (d.repack_every == 0 && d.B >= 32768 ? 8 : 0);
     }
+    // off unless asked for: beside the bandwidth-bound commit the latency-bound second stage runs
+    // 2.5x slower and slows the commit down (measured: 34.8 -> 42.0 ms per solve at B = 65536)
+    h->overlap = d.overlap_stages > 0 && h->n_parts == 1;
     *out = h;
     return ILQR_OK;
 }
@@ -291,6 +298,9 @@ void ilqr_destroy(ilqr_handle *h) {
         }
         if (h->fork_event) (void)hipEventDestroy(h->fork_event);
     }
+    if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
 }
 
@@ -324,6 +334,21 @@ int ilqr_bind(ilqr_handle *h, const ilqr_buffers *b) {
     if (!(h)) return ILQR_ERR_INVALID;            \
     if (!(h)->ctx.bound) return ILQR_ERR_NOT_BOUND;
 
+// the handle's own stream for the second line-search stage (created on first use, on the device
+// that is current then)
+static hipError_t ensure_side(ilqr_handle *h) {
+    if (!h->overlap || h->side) return hipSuccess;
+    hipError_t e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) {
+        h->ctx.side = h->side;
+        h->ctx.ev_fork = h->ev_fork;
+        h->ctx.ev_join = h->ev_join;
+    }
+    return e;
+}
+
 // launch context of the phase calls: the handle's settings with the whole-batch compaction state
 static HostCtx &phase_ctx(ilqr_handle *h) {
     h->whole.ctx.d = h->ctx.d;
@@ -338,6 +363,9 @@ static HostCtx &phase_ctx(ilqr_handle *h) {
     h->whole.ctx.reroll = h->ctx.reroll;
     h->whole.ctx.select_converged = false;
     h->whole.ctx.eval_stages = 3;
+    h->whole.ctx.side = h->ctx.side;
+    h->whole.ctx.ev_fork = h->ctx.ev_fork;
+    h->whole.ctx.ev_join = h->ctx.ev_join;
     return h->whole.ctx;
 }
 
@@ -358,12 +386,14 @@ int ilqr_backward(ilqr_handle *h, void *stream) {
 
 int ilqr_forward_evaluate(ilqr_handle *h, void *stream) {
     REQUIRE_BOUND(h);
+    if (hipError_t e = ensure_side(h); e != hipSuccess) return hip_rc(e);
     return hip_rc(h->ops->evaluate(phase_ctx(h), 0, (hipStream_t)stream));
 }
 
 int ilqr_forward_evaluate_stage(ilqr_handle *h, int32_t stage, void *stream) {
     REQUIRE_BOUND(h);
     if (stage != 0 && stage != 1) return ILQR_ERR_INVALID;
+    if (hipError_t e = ensure_side(h); e != hipSuccess) return hip_rc(e);
     HostCtx c = phase_ctx(h);
     c.eval_stages = stage == 0 ? 1 : 2;
     return hip_rc(h->ops->evaluate(c, 0, (hipStream_t)stream));
@@ -372,6 +402,7 @@ int ilqr_forward_evaluate_stage(ilqr_handle *h, int32_t stage, void *stream) {
 int ilqr_forward_commit(ilqr_handle *h, int32_t iteration, void *stream) {
     REQUIRE_BOUND(h);
     if (iteration < 0) return ILQR_ERR_INVALID;
+    if (hipError_t e = ensure_side(h); e != hipSuccess) return hip_rc(e);
     const int rc = hip_rc(h->ops->commit(phase_ctx(h), iteration, (hipStream_t)stream));
     // every problem that is still active afterwards has had a step committed by this library
     if (rc == ILQR_OK && h->ctx.d.recompute_states >= 0) h->ctx.reroll = true;
@@ -406,6 +437,7 @@ int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream) {
     REQUIRE_BOUND(h);
     if (max_iter < 0) return ILQR_ERR_INVALID;
     REQUIRE_UNPACKED(h);
+    if (hipError_t e0 = ensure_side(h); e0 != hipSuccess) return hip_rc(e0);
     hipStream_t user = (hipStream_t)stream;
     const int np = h->n_parts;
     hipError_t e = hipSuccess;

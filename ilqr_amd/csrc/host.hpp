@@ -26,6 +26,10 @@ struct HostCtx {
     bool reroll = false;
     bool select_converged = false; // backward pass: recompute the gains of the converged problems
     int eval_stages = 3;           // line search: bit 0 = stage one, bit 1 = stage two (see evaluate_kernel)
+    // stage two fused with the commit of its problems, beside the commit of the others: the stream
+    // and events it runs on (null: stage two runs before the commit, on the caller's stream)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // working set of ilqr_solve's active-set compaction: when `slot2orig` is set, the tiled
     // arrays below replace the bound ones (they are already relative to this part and hold
     // *nslots problems in slot order) and the per-problem arrays are indexed through the map
@@ -267,17 +271,25 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
             if (e == hipSuccess) e = eval_stage_one<BARRIER, L, A, REROLL>(c, s, first_end);
             if (e != hipSuccess) return e;
         }
-        if (!two || !(c.eval_stages & 2)) return hipSuccess;
+        if (!two || !(c.eval_stages & 2) || c.side != nullptr) return hipSuccess;
+        return launch_listed<BARRIER, REROLL, false>(c, s, first_end, 0);
+    }
+    // stage two over the listed problems; COMMIT: it also commits them (see evaluate_listed_kernel)
+    template <bool BARRIER, bool REROLL, bool COMMIT>
+    static hipError_t launch_listed(const HostCtx &c, hipStream_t s, int first_end, int it) {
+        auto p = make_params<T, NX, NU>(c);
         // the length of the list is only known on the device: the grid covers the worst case and
         // the waves beyond the list leave at once
         // one round of stage two should cover all remaining candidates: 8 lanes per listed problem
         // if at most 8 remain, else 16
         if (M::NX > 8 || c.n_alphas - first_end > 8) {
             const int blocks = (int)(((long)c.count + 3) / 4); // one wave per workgroup, 4 problems per wave
-            hipLaunchKernelGGL((evaluate_listed_kernel<T, M, DIAG, BARRIER, 16, REROLL>), dim3(blocks), dim3(64), 0, s, p, first_end, c.n_alphas);
+            hipLaunchKernelGGL((evaluate_listed_kernel<T, M, DIAG, BARRIER, 16, REROLL, COMMIT>), dim3(blocks), dim3(64), 0, s, p, first_end,
+                               c.n_alphas, it);
         } else if constexpr (M::NX <= 8) {
             const int blocks = (int)(((long)c.count + 7) / 8);
-            hipLaunchKernelGGL((evaluate_listed_kernel<T, M, DIAG, BARRIER, 8, REROLL>), dim3(blocks), dim3(64), 0, s, p, first_end, c.n_alphas);
+            hipLaunchKernelGGL((evaluate_listed_kernel<T, M, DIAG, BARRIER, 8, REROLL, COMMIT>), dim3(blocks), dim3(64), 0, s, p, first_end,
+                               c.n_alphas, it);
         }
         return hipGetLastError();
     }
@@ -353,8 +365,40 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
         hipLaunchKernelGGL((commit_kernel<T, M, PF_COMMIT, REROLL>), dim3((c.count + 63) / 64), dim3(64), 0, s, p, it);
         return hipGetLastError();
     }
+    // number of candidates of the first line-search stage; >= n_alphas: there is no second stage
+    static int first_stage_candidates(const HostCtx &c) {
+        if constexpr (std::is_same<T, double>::value && std::is_same<M, LtvModelT<double, 12, 4>>::value && DIAG) {
+            static const bool generic = getenv("ILQR_LTV_GENERIC") != nullptr;
+            if (!barrier_on(c) && c.n_alphas <= 16 && !generic) return 16;
+        }
+        return c.L * c.A;
+    }
+    template <bool REROLL> static hipError_t commit_all(const HostCtx &c, int it, hipStream_t s) {
+        const int first_end = first_stage_candidates(c);
+        const bool beside = c.side != nullptr && first_end < c.n_alphas;
+        hipError_t e = hipSuccess;
+        if (beside) {
+            // fork: the listed problems are decided and committed on the side stream while the
+            // commit of all others runs here (the two never touch the same problem)
+            e = hipEventRecord(c.ev_fork, s);
+            if (e == hipSuccess) e = hipStreamWaitEvent(c.side, c.ev_fork, 0);
+            if (e == hipSuccess) {
+                if constexpr (M::HAS_BARRIER) {
+                    e = barrier_on(c) ? launch_listed<true, REROLL, true>(c, c.side, first_end, it)
+                                      : launch_listed<false, REROLL, true>(c, c.side, first_end, it);
+                } else {
+                    e = launch_listed<false, REROLL, true>(c, c.side, first_end, it);
+                }
+            }
+            if (e == hipSuccess) e = hipEventRecord(c.ev_join, c.side);
+            if (e != hipSuccess) return e;
+        }
+        e = commit_r<REROLL>(c, it, s);
+        if (beside && e == hipSuccess) e = hipStreamWaitEvent(s, c.ev_join, 0);
+        return e;
+    }
     static hipError_t commit(const HostCtx &c, int it, hipStream_t s) {
-        return c.reroll ? commit_r<true>(c, it, s) : commit_r<false>(c, it, s);
+        return c.reroll ? commit_all<true>(c, it, s) : commit_all<false>(c, it, s);
     }
     static const ModelOps *table() {
         static const ModelOps ops = {&cost, &backward, &evaluate, &commit};

@@ -1180,7 +1180,10 @@ __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T,
         int at = 0;
         if (lane == 0) at = atomicAdd(p.list_count, __popcll(mm));
         at = __shfl(at, 0) + __popcll(mm & ((1ull << lane) - 1ull));
-        if (more) p.list[at] = b;
+        if (more) {
+            p.list[at] = b;
+            p.alpha_idx[o] = -2; // pending: stage two (or the commit that runs beside it) decides
+        }
     }
     if (active && al == 0 && !more) {
         p.alpha_idx[o] = found ? best : -1;
@@ -1216,16 +1219,17 @@ template <typename T, class M, bool BARRIER, int L, bool REROLL> struct ListedSt
     T Cc[BARRIER ? C::cnt(C::nC) : 1], D[BARRIER ? C::cnt(C::nD) : 1];
 };
 
-template <typename T, class M, bool DIAG, bool BARRIER, int L, bool REROLL, bool FAST, class P>
-__device__ __forceinline__ void listed_rounds(const P &p, const T *Xt, const T *Rt, const T *Ut, const T *Kp, const T *kp,
-                                              const T *Cp, const T *Dp, T *lds, int al, bool active, T Jcur, int base0, int end,
-                                              int &best, T &best_cost, bool &bad) {
+// The block pipeline of stage two: global rows -> registers (one block ahead) -> LDS -> FwdRow.
+template <typename T, class M, bool BARRIER, int L, bool REROLL> struct ListedPipe {
     using C = ListedCfg<M, BARRIER, L, REROLL>;
-    constexpr int NX = M::NX, NU = M::NU, SB = C::SB;
-    const int T1 = p.N - 1;
+    using Stage = ListedStage<T, M, BARRIER, L, REROLL>;
+    static constexpr int NX = M::NX, NU = M::NU;
+    const T *Xt, *Rt, *Ut, *Kp, *kp, *Cp, *Dp;
+    T *lds;
+    int al, N, T1;
     // rows [r0, r0 + n) of an array with `rows` rows per problem: lane al takes every L-th; past
     // either end the nearest valid row is fetched instead (no branch around a load)
-    auto fetch = [&](const T *src, int r0, int n, int rows, auto &dst) {
+    template <class D> __device__ __forceinline__ void fetch(const T *src, int r0, int n, int rows, D &dst) const {
 #pragma unroll
         for (int i = 0; i < C::cnt(n); ++i) {
             int e = al + L * i;
@@ -1234,26 +1238,66 @@ __device__ __forceinline__ void listed_rounds(const P &p, const T *Xt, const T *
             r = r < rows ? r : rows - 1;
             dst[i] = src[(size_t)r * TILE];
         }
-    };
-    auto put = [&](int off, int n, const auto &src) {
+    }
+    template <class D> __device__ __forceinline__ void put(int off, int n, const D &src) const {
 #pragma unroll
         for (int i = 0; i < C::cnt(n); ++i) {
             int e = al + L * i;
             e = e < n ? e : n - 1;
             lds[off + e] = src[i];
         }
-    };
-    auto fetch_block = [&](int t0, ListedStage<T, M, BARRIER, L, REROLL> &st) {
+    }
+    __device__ __forceinline__ void fetch_block(int t0, Stage &st) const {
         fetch(Kp, t0 * NU * NX, C::nK, T1 * NU * NX, st.K);
         fetch(kp, t0 * NU, C::nk, T1 * NU, st.k);
         fetch(Ut, t0 * NU, C::nk, T1 * NU, st.U);
-        if (!REROLL) fetch(Xt, t0 * NX, C::nX, p.N * NX, st.X);
-        fetch(Rt, t0 * NX, C::nX, p.N * NX, st.R);
+        if (!REROLL) fetch(Xt, t0 * NX, C::nX, N * NX, st.X);
+        fetch(Rt, t0 * NX, C::nX, N * NX, st.R);
         if (BARRIER) {
-            fetch(Cp, t0 * 2, C::nC, p.N * 2, st.Cc);
-            fetch(Dp, t0, C::nD, p.N, st.D);
+            fetch(Cp, t0 * 2, C::nC, N * 2, st.Cc);
+            fetch(Dp, t0, C::nD, N, st.D);
         }
-    };
+    }
+    __device__ __forceinline__ void put_block(const Stage &st) const {
+        put(C::oK, C::nK, st.K);
+        put(C::ok, C::nk, st.k);
+        put(C::oU, C::nk, st.U);
+        if (!REROLL) put(C::oX, C::nX, st.X);
+        put(C::oR, C::nX, st.R);
+        if (BARRIER) {
+            put(C::oC, C::nC, st.Cc);
+            put(C::oD, C::nD, st.D);
+        }
+    }
+    __device__ __forceinline__ void read_row(int s, FwdRow<T, NX, NU> &r) const {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            r.k[i] = lds[C::ok + s * NU + i];
+            r.up[i] = lds[C::oU + s * NU + i];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) r.K[i][j] = lds[C::oK + (s * NU + i) * NX + j];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            if (!REROLL) r.xp[i] = lds[C::oX + s * NX + i];
+            r.xr[i] = lds[C::oR + s * NX + i];
+        }
+        if (BARRIER) {
+            r.cx = lds[C::oC + s * 2 + 0];
+            r.cy = lds[C::oC + s * 2 + 1];
+            r.rad = lds[C::oD + s];
+        } else {
+            r.cx = r.cy = r.rad = T(0);
+        }
+    }
+};
+
+template <typename T, class M, bool DIAG, bool BARRIER, int L, bool REROLL, bool FAST, class P>
+__device__ __forceinline__ void listed_rounds(const P &p, const ListedPipe<T, M, BARRIER, L, REROLL> &pipe, bool active, T Jcur, int base0,
+                                              int end, int &best, T &best_cost, bool &bad) {
+    using C = ListedCfg<M, BARRIER, L, REROLL>;
+    constexpr int NX = M::NX, NU = M::NU, SB = C::SB;
+    const int T1 = p.N - 1, al = pipe.al;
     best = 0x7fffffff;
     best_cost = T(0);
     for (int base = base0; base < end; base += L) {
@@ -1261,52 +1305,23 @@ __device__ __forceinline__ void listed_rounds(const P &p, const T *Xt, const T *
         const T alpha = pow2_neg<T>(a);
         T x[NX], cost = T(0);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) x[i] = Xt[i * TILE];
+        for (int i = 0; i < NX; ++i) x[i] = pipe.Xt[i * TILE];
         T xq[NX]; // state of the previous trajectory (REROLL)
 #pragma unroll
         for (int i = 0; i < NX; ++i) xq[i] = x[i];
-        ListedStage<T, M, BARRIER, L, REROLL> st;
-        fetch_block(0, st);
+        typename ListedPipe<T, M, BARRIER, L, REROLL>::Stage st;
+        pipe.fetch_block(0, st);
         for (int t0 = 0; t0 < T1; t0 += SB) {
             __syncthreads(); // the rollout of the previous block has read its rows
-            put(C::oK, C::nK, st.K);
-            put(C::ok, C::nk, st.k);
-            put(C::oU, C::nk, st.U);
-            if (!REROLL) put(C::oX, C::nX, st.X);
-            put(C::oR, C::nX, st.R);
-            if (BARRIER) {
-                put(C::oC, C::nC, st.Cc);
-                put(C::oD, C::nD, st.D);
-            }
+            pipe.put_block(st);
             __syncthreads();
-            fetch_block(t0 + SB, st); // in flight during the rollout below
+            pipe.fetch_block(t0 + SB, st); // in flight during the rollout below
             const int ns = T1 - t0 < SB ? T1 - t0 : SB;
-            auto read_row = [&](int s, FwdRow<T, NX, NU> &r) {
-#pragma unroll
-                for (int i = 0; i < NU; ++i) {
-                    r.k[i] = lds[C::ok + s * NU + i];
-                    r.up[i] = lds[C::oU + s * NU + i];
-#pragma unroll
-                    for (int j = 0; j < NX; ++j) r.K[i][j] = lds[C::oK + (s * NU + i) * NX + j];
-                }
-#pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    if (!REROLL) r.xp[i] = lds[C::oX + s * NX + i];
-                    r.xr[i] = lds[C::oR + s * NX + i];
-                }
-                if (BARRIER) {
-                    r.cx = lds[C::oC + s * 2 + 0];
-                    r.cy = lds[C::oC + s * 2 + 1];
-                    r.rad = lds[C::oD + s];
-                } else {
-                    r.cx = r.cy = r.rad = T(0);
-                }
-            };
             FwdRow<T, NX, NU> rn;
-            read_row(0, rn);
+            pipe.read_row(0, rn);
             for (int s = 0; s < ns; ++s) {
                 FwdRow<T, NX, NU> r = rn;
-                read_row(s + 1 < SB ? s + 1 : s, rn); // the next step's row leaves LDS during this step
+                pipe.read_row(s + 1 < SB ? s + 1 : s, rn); // the next step's row leaves LDS during this step
                 if (REROLL) {
 #pragma unroll
                     for (int i = 0; i < NX; ++i) r.xp[i] = xq[i];
@@ -1322,11 +1337,11 @@ __device__ __forceinline__ void listed_rounds(const P &p, const T *Xt, const T *
         }
         T xr[NX], cx = T(0), cy = T(0), rad = T(0);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xr[i] = Rt[(T1 * NX + i) * TILE];
+        for (int i = 0; i < NX; ++i) xr[i] = pipe.Rt[(T1 * NX + i) * TILE];
         if (BARRIER) {
-            cx = Cp[(T1 * 2 + 0) * TILE];
-            cy = Cp[(T1 * 2 + 1) * TILE];
-            rad = Dp[T1 * TILE];
+            cx = pipe.Cp[(T1 * 2 + 0) * TILE];
+            cy = pipe.Cp[(T1 * 2 + 1) * TILE];
+            rad = pipe.Dp[T1 * TILE];
         }
         const T c = candidate_total<T, M, DIAG, BARRIER>(p, x, xr, cx, cy, rad, cost);
         int cand = 0x7fffffff;
@@ -1352,10 +1367,63 @@ __device__ __forceinline__ void listed_rounds(const P &p, const T *Xt, const T *
     }
 }
 
+// The accepted step of the listed problems rolled out once more and written in place (what
+// commit_kernel does for the others), through the same block pipeline: every lane of a problem
+// computes the same rollout and its first lane stores.  A block's rows are in LDS and the next
+// block's in registers before any row of the block is overwritten.
+template <typename T, class M, bool BARRIER, int L, bool REROLL, bool FAST, class P>
+__device__ __forceinline__ void listed_commit(const P &p, const ListedPipe<T, M, BARRIER, L, REROLL> &pipe, T *Xw, T *Uw, T alpha,
+                                              bool store) {
+    using C = ListedCfg<M, BARRIER, L, REROLL>;
+    constexpr int NX = M::NX, NU = M::NU, SB = C::SB;
+    const int T1 = p.N - 1;
+    T x[NX], xq[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xq[i] = x[i] = pipe.Xt[i * TILE];
+    typename ListedPipe<T, M, BARRIER, L, REROLL>::Stage st;
+    pipe.fetch_block(0, st);
+    bool bad = false;
+    for (int t0 = 0; t0 < T1; t0 += SB) {
+        __syncthreads();
+        pipe.put_block(st);
+        __syncthreads();
+        pipe.fetch_block(t0 + SB, st);
+        const int ns = T1 - t0 < SB ? T1 - t0 : SB;
+        for (int s = 0; s < ns; ++s) {
+            const int t = t0 + s;
+            FwdRow<T, NX, NU> r;
+            pipe.read_row(s, r);
+            if (REROLL) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) r.xp[i] = xq[i];
+            }
+            T un[NU], xn[NX];
+            control_update<T, M>(p, alpha, x, r.xp, r.up, r.K, r.k, un);
+            M::template step<FAST>(p, t, x, un, xn, bad);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = xn[i];
+            if (REROLL) {
+                T xqn[NX];
+                M::template step<FAST>(p, t, xq, r.up, xqn, bad);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xq[i] = xqn[i];
+            }
+            if (store) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) Uw[(size_t)(t * NU + i) * TILE] = un[i];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) Xw[(size_t)((t + 1) * NX + i) * TILE] = xn[i];
+            }
+        }
+    }
+}
+
 // one wave per workgroup; the grid covers the worst case (every problem listed) and the waves
-// beyond the end of the list leave at once
-template <typename T, class M, bool DIAG, bool BARRIER, int L, bool REROLL>
-__global__ __launch_bounds__(64) void evaluate_listed_kernel(Params<T, M::NX, M::NU> p, int base0, int end) {
+// beyond the end of the list leave at once.  COMMIT: the kernel also commits the outcome of its
+// problems (state, input, cost, flags and history exactly as commit_kernel would), so that it
+// can run beside the commit of all other problems instead of before it.
+template <typename T, class M, bool DIAG, bool BARRIER, int L, bool REROLL, bool COMMIT>
+__global__ __launch_bounds__(64) void evaluate_listed_kernel(Params<T, M::NX, M::NU> p, int base0, int end, int it) {
     using C = ListedCfg<M, BARRIER, L, REROLL>;
     constexpr int NX = M::NX, NU = M::NU, PPW = C::PPW;
     __shared__ T rows[C::LDS];
@@ -1371,18 +1439,22 @@ __global__ __launch_bounds__(64) void evaluate_listed_kernel(Params<T, M::NX, M:
     const int T1 = p.N - 1;
     const T Jcur = p.J[o];
     const int tile = b >> 6, ln = b & 63;
-    const T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
-    const T *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
-    const T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
-    const T *Cp = BARRIER ? tile_ptr(p.centers, tile, p.N * 2, ln) : nullptr;
-    const T *Dp = BARRIER ? tile_ptr(p.radius, tile, p.N, ln) : nullptr;
-    const T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
-    const T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
-    T *lds = rows + pl * C::STRIDE;
+    ListedPipe<T, M, BARRIER, L, REROLL> pipe;
+    pipe.Xt = tile_ptr(p.X, tile, p.N * NX, ln);
+    pipe.Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
+    pipe.Ut = tile_ptr(p.U, tile, T1 * NU, ln);
+    pipe.Cp = BARRIER ? tile_ptr(p.centers, tile, p.N * 2, ln) : nullptr;
+    pipe.Dp = BARRIER ? tile_ptr(p.radius, tile, p.N, ln) : nullptr;
+    pipe.kp = tile_ptr(p.k, tile, T1 * NU, ln);
+    pipe.Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    pipe.lds = rows + pl * C::STRIDE;
+    pipe.al = al;
+    pipe.N = p.N;
+    pipe.T1 = T1;
     int best;
     T best_cost;
     bool bad = false;
-    listed_rounds<T, M, DIAG, BARRIER, L, REROLL, true>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, lds, al, active, Jcur, base0, end, best, best_cost, bad);
+    listed_rounds<T, M, DIAG, BARRIER, L, REROLL, true>(p, pipe, active, Jcur, base0, end, best, best_cost, bad);
     bool pbad = bad; // as in evaluate_kernel
 #pragma unroll
     for (int w = 1; w < L; w <<= 1) pbad |= __shfl_xor((int)pbad, w) != 0;
@@ -1390,16 +1462,49 @@ __global__ __launch_bounds__(64) void evaluate_listed_kernel(Params<T, M::NX, M:
         int best2;
         T best_cost2;
         bool bad2 = false;
-        listed_rounds<T, M, DIAG, BARRIER, L, REROLL, false>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, lds, al, active, Jcur, base0, end, best2, best_cost2, bad2);
+        listed_rounds<T, M, DIAG, BARRIER, L, REROLL, false>(p, pipe, active, Jcur, base0, end, best2, best_cost2, bad2);
         best = pbad ? best2 : best;
         best_cost = pbad ? best_cost2 : best_cost;
     }
-    if (active && al == 0) {
-        const bool found = best != 0x7fffffff;
-        p.alpha_idx[o] = found ? best : -1;
-        p.Jtry[o] = best_cost;
-        p.slow_trig[o] = (p.slow_trig[o] & 6) | (pbad ? 1 : 0);
+    const bool found = best != 0x7fffffff;
+    if (!COMMIT) {
+        if (active && al == 0) {
+            p.alpha_idx[o] = found ? best : -1;
+            p.Jtry[o] = best_cost;
+            p.slow_trig[o] = (p.slow_trig[o] & 6) | (pbad ? 1 : 0);
+        }
+        return;
     }
+    // commit (mirrors commit_kernel for these problems)
+    const bool roll = active && found;
+    const bool wave_slow = __ballot(roll && pbad) != 0ull;
+    if (active && al == 0) {
+        const int idx = found ? best : -1;
+        p.alpha_idx[o] = idx;
+        p.Jtry[o] = best_cost;
+        const int bits = (p.slow_trig[o] & 6) | (pbad ? 1 : 0);
+        const int committed = roll ? (4 | (wave_slow ? 2 : 0)) : 0;
+        p.slow_trig[o] = REROLL ? (bits | committed) : ((bits & 1) | committed);
+        p.iters[o] += 1;
+        const T Jn = roll ? best_cost : Jcur;
+        if (roll) {
+            p.J[o] = Jn;
+            if (p.status && !(fabs_(Jn) < inf_<T>())) p.status[o] |= ILQR_STATUS_NONFINITE_;
+        } else {
+            p.converged[o] = 1;
+        }
+        if (it < p.hist_cap) {
+            if (p.hist_cost) p.hist_cost[size_t(it) * p.hist_stride + o] = Jn;
+            if (p.hist_alpha) p.hist_alpha[size_t(it) * p.hist_stride + o] = idx;
+        }
+    }
+    if (__ballot(roll) == 0ull) return;
+    const T alpha = pow2_neg<T>(roll ? best : 0);
+    T *Xw = tile_ptr(p.X, tile, p.N * NX, ln), *Uw = tile_ptr(p.U, tile, T1 * NU, ln);
+    if (!wave_slow)
+        listed_commit<T, M, BARRIER, L, REROLL, true>(p, pipe, Xw, Uw, alpha, roll && al == 0);
+    else
+        listed_commit<T, M, BARRIER, L, REROLL, false>(p, pipe, Xw, Uw, alpha, roll && al == 0);
 }
 
 // ---------------------------------------------------------------- line search, n = 12, m = 4, fp64
@@ -1528,7 +1633,7 @@ static __global__ __launch_bounds__(1024) void ltv12x4_evaluate_mfma_kernel(Para
 // stores go to a scratch slot `trash` (still no branch around the stores).
 template <typename T, class M, int PF, bool REROLL, bool FAST, class P>
 __device__ __forceinline__ void commit_sweep(const P &p, T *Xt, T *Ut, const T *Kp, const T *kp, T *trash, T alpha, bool roll,
-                                             bool keep_ok) {
+                                             bool keep_ok, bool pend) {
     constexpr int NX = M::NX, NU = M::NU;
     const int T1 = p.N - 1;
     struct Row {
@@ -1579,18 +1684,24 @@ __device__ __forceinline__ void commit_sweep(const P &p, T *Xt, T *Ut, const T *
         }
         // Every lane stores; a lane whose problem has no accepted step writes back the values it
         // read (no branch around the stores: see backward_sweep)
+        // `pend`: the problem is being decided and committed by the second line-search stage,
+        // which may run beside this kernel: nothing of it may be written here
 #pragma unroll
-        for (int i = 0; i < NU; ++i) Ut[(t * NU + i) * TILE] = roll ? un[i] : r.up[i];
+        for (int i = 0; i < NU; ++i) {
+            T *dst = pend ? trash : &Ut[(t * NU + i) * TILE];
+            *dst = roll ? un[i] : r.up[i];
+        }
         // the recomputed old states are the stored ones only while the fast trigonometry was in
         // range (the library routine may differ from it in the last bit)
-        const bool real = roll || (FAST && keep_ok && !badq);
+        const bool real = roll || (!pend && FAST && keep_ok && !badq);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             if (REROLL) {
                 T *dst = real ? &Xt[((t + 1) * NX + i) * TILE] : trash;
                 *dst = roll ? xn[i] : xq[i];
             } else {
-                Xt[((t + 1) * NX + i) * TILE] = roll ? xn[i] : (t + 1 < T1 ? nxt.xp[i] : xlast[i]);
+                T *dst = pend ? trash : &Xt[((t + 1) * NX + i) * TILE];
+                *dst = roll ? xn[i] : (t + 1 < T1 ? nxt.xp[i] : xlast[i]);
             }
         }
     }
@@ -1612,8 +1723,9 @@ __global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, i
     T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
     const T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
     const T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
-    T *trash = REROLL ? p.trash + b0 : nullptr;
+    T *trash = p.trash + b0;
     const int idx = p.alpha_idx[b];
+    const bool pend = active && idx == -2; // listed for the second line-search stage, which also commits it
     const bool roll = active && idx >= 0;
     // slow_trig bits: 1 = this line search needed the library sine/cosine (set by the evaluate
     // kernels); 2 = some step of this problem was committed by the library-routine sweep;
@@ -1625,14 +1737,14 @@ __global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, i
     const bool wave_slow = __ballot(slow) != 0ull;
     // stored states = this code's fast-path rollout of the stored inputs
     const bool keep_ok = !valid || (slow_bits & 6) == 4;
-    if (valid) {
+    if (valid && !pend) {
         const int committed = roll ? (4 | (wave_slow ? 2 : 0)) : 0;
         if (!REROLL)
             p.slow_trig[b] = (slow_bits & 1) | committed;
         else if (roll)
             p.slow_trig[b] = slow_bits | committed;
     }
-    if (active) {
+    if (active && !pend) {
         p.iters[b] += 1;
         T Jn = roll ? p.Jtry[b] : p.J[b];
         if (roll) {
@@ -1651,9 +1763,9 @@ __global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, i
     // the trajectory is overwritten in place, so the choice between the fast trigonometry and
     // the library routine is made up front, from what the evaluate kernel saw on these problems
     if (!wave_slow)
-        commit_sweep<T, M, PF, REROLL, true>(p, Xt, Ut, Kp, kp, trash, alpha, roll, keep_ok);
+        commit_sweep<T, M, PF, REROLL, true>(p, Xt, Ut, Kp, kp, trash, alpha, roll, keep_ok, pend);
     else
-        commit_sweep<T, M, 1, REROLL, false>(p, Xt, Ut, Kp, kp, trash, alpha, roll, keep_ok);
+        commit_sweep<T, M, 1, REROLL, false>(p, Xt, Ut, Kp, kp, trash, alpha, roll, keep_ok, pend);
 }
 
 // ---------------------------------------------------------------- active-set compaction

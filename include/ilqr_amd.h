@@ -90,6 +90,12 @@ typedef struct ilqr_desc {
     int32_t recompute_states;  /* >= 0: once a step has been committed, the forward kernels roll the previous
                                   states out again from U instead of reading X (same bits, less traffic);
                                   < 0: always read X */
+    int32_t overlap_stages;    /* > 0: the second line-search stage also commits its problems and runs beside the
+                                  commit of the others, on a stream of the handle's own (ilqr_forward_commit then
+                                  launches it; ilqr_forward_evaluate_stage 1 does nothing); <= 0 (default): it
+                                  runs before the commit, on the caller's stream.  Same results either way;
+                                  slower on MI355X at B = 65536 (the two kernels fight over memory). */
+    int32_t reserved2;
     double dt;               /* system.dt (systems.py:30); the solver's own dt argument is unused (ilqr.py:20) */
     double lm_parameter;     /* ilqr.py:30, added to Vxx (ilqr.py:95) */
     double alpha_floor;      /* 1e-4 (ilqr.py:71) or alpha_terminal (cilqr.py:41) */

@@ -190,12 +190,13 @@ def test_recomputing_previous_states_does_not_change_a_bit(ilqr_cls):
     for b in range(5):
         p["init_states"][b] = p["target_states"][b]
         p["init_inputs"][b] = 0.0
-    ref = _solve_batch(ilqr_cls, p, recompute_states=-1)
+    ref = _solve_batch(ilqr_cls, p, recompute_states=-1, overlap_stages=-1, lanes_per_problem=2, alphas_per_lane=8)
     Kr, kr = ref.K.copy(), ref.k.copy()
     assert ref.converge[:5].all() and (ref.iterations[:5] == 1).all()
     assert np.array_equal(ref.states[:5], p["target_states"][:5])
     assert (ref.iterations > 3).any()
-    for kw in (dict(), dict(lanes_per_problem=1, alphas_per_lane=8), dict(lanes_per_problem=8, alphas_per_lane=2, n_streams=2),
+    for kw in (dict(), dict(overlap_stages=1), dict(lanes_per_problem=1, alphas_per_lane=6, overlap_stages=1, repack_every=4),
+               dict(lanes_per_problem=1, alphas_per_lane=8), dict(lanes_per_problem=8, alphas_per_lane=2, n_streams=2),
                dict(lanes_per_problem=2, alphas_per_lane=4, repack_every=3)):
         o = _solve_batch(ilqr_cls, p, recompute_states=0, **kw)
         for key in ("states", "inputs", "min_cost", "iterations", "converge", "status"):
