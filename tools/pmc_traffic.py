@@ -9,7 +9,8 @@ request, so a coalesced streaming read reports exactly half its bytes and is dou
 (checked in the same run on cost_kernel, a pure streaming read of X, U and Xref with the access
 shape of all solver kernels: 8 B per lane, 512 B per wave instruction); WRITE_SIZE is exact for
 these stores (checked on relayout_kernel).  Reported per launch, as the mean over the launches
-of one bench.py step (all template variants of a kernel together), under the names bench.py uses.
+of one bench.py step that did work (all template variants of a kernel together), under the names
+bench.py uses.
 """
 import collections
 import csv
@@ -44,7 +45,10 @@ def main():
     wr = per_launch(write_dir, "WRITE_SIZE", 1024.0)
     res = {}
     for key in rd:
-        r, w = rd[key], wr.get(key, [0.0])
+        # launches that leave at once (an idle line-search mapping, an empty list) are not counted
+        keep = [i for i, v in enumerate(rd[key]) if v > 1e6] or list(range(len(rd[key])))
+        r = [rd[key][i] for i in keep]
+        w = [wr[key][i] for i in keep] if key in wr and len(wr[key]) == len(rd[key]) else wr.get(key, [0.0])
         res[key] = {"launches": len(r), "read_bytes_per_launch": sum(r) / len(r), "write_bytes_per_launch": sum(w) / len(w),
                     "bytes_per_launch": sum(r) / len(r) + sum(w) / len(w), "max_bytes_per_launch": max(r) + max(w)}
     txt = json.dumps(res, indent=1)
