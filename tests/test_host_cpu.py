@@ -79,6 +79,39 @@ def test_create_validates_descriptor():
     assert b"bound" in lib.ilqr_strerror(-3)
 
 
+def test_auto_choices_and_workspace_of_a_handle():
+    """Host-only decisions of ilqr_create: the forward mapping picked for 0 = auto, the size
+    threshold of active-set compaction (visible through the workspace the handle asks for) and
+    the refusal of the phase-level entry points on an unbound handle."""
+    lib = _lib.lib()
+
+    def mapping(h):
+        L, A = C.c_int32(0), C.c_int32(0)
+        assert lib.ilqr_forward_mapping(h, C.byref(L), C.byref(A)) == 0
+        return L.value, A.value
+
+    rc, h = _create(_desc(B=65536, N=200))
+    assert rc == 0 and mapping(h) == (1, 6)          # six candidates in the first stage, the rest in the second
+    big = lib.ilqr_workspace_bytes(h)
+    lib.ilqr_destroy(h)
+    rc, h = _create(_desc(B=65536, N=200, repack_every=-1))
+    small = lib.ilqr_workspace_bytes(h)
+    assert rc == 0 and small < big                   # two working sets of X, U, Xref plus working gains
+    assert big - small >= 2 * 65536 * (2 * 200 * 4 + 199 * 2) * 8
+    lib.ilqr_destroy(h)
+    rc, h = _create(_desc(B=4096, N=200))
+    assert rc == 0 and mapping(h) == (8, 1)          # small batch: more lanes per problem
+    assert lib.ilqr_workspace_bytes(h) < 4096 * 200 * 4 * 8   # below the compaction threshold
+    for fn in (lib.ilqr_repack, lib.ilqr_unpack, lib.ilqr_initial_cost, lib.ilqr_forward_evaluate):
+        assert fn(h, None) == -3
+    assert lib.ilqr_forward_evaluate_stage(h, 1, None) == -3
+    assert lib.ilqr_shift(h, 1, None, None) == -3
+    lib.ilqr_destroy(h)
+    rc, h = _create(_desc(alpha_floor=1e-2, B=65536))
+    assert rc == 0 and mapping(h) == (1, 8)          # 8 step sizes (cilqr.py:41): a single stage
+    lib.ilqr_destroy(h)
+
+
 def test_systems_interface_matches_reference_surface():
     car = systems.Car()
     assert (car.state_size, car.control_size, car.dt, car.control_limited) == (4, 2, 0.2, False)
