@@ -224,16 +224,16 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
     }
     static hipError_t backward(const HostCtx &c, int, hipStream_t s) {
         const int mode = c.d.constraint_mode & 3;
-        if constexpr (std::is_same<T, double>::value && std::is_same<M, LtvModelT<double, 12, 4>>::value && DIAG) {
-            // one wave per problem on the fp64 matrix unit (kernels.hpp); the lane-per-problem
+        if constexpr (std::is_same<M, LtvModelT<T, 12, 4>>::value && DIAG) {
+            // one wave per problem on the matrix unit (kernels.hpp); the lane-per-problem
             // kernel remains for the box-QP mode and as the cross-check (ILQR_LTV_GENERIC=1)
             static const bool generic = getenv("ILQR_LTV_GENERIC") != nullptr;
             if (mode == 0 && !generic) {
                 auto p = make_params<T, NX, NU>(c);
                 const int tiles = (c.count + 63) / 64;
                 const int blocks = ((tiles + 7) / 8) * 8 * 64;
-                hipLaunchKernelGGL(ltv12x4_backward_mfma_kernel<false>, dim3(blocks), dim3(64), 0, s, p);
-                hipLaunchKernelGGL(ltv12x4_backward_mfma_kernel<true>, dim3(blocks), dim3(64), 0, s, p);
+                hipLaunchKernelGGL((ltv12x4_backward_mfma_kernel<T, false>), dim3(blocks), dim3(64), 0, s, p);
+                hipLaunchKernelGGL((ltv12x4_backward_mfma_kernel<T, true>), dim3(blocks), dim3(64), 0, s, p);
                 return hipGetLastError();
             }
         }
@@ -344,13 +344,16 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
         }
     }
     static hipError_t evaluate(const HostCtx &c, int, hipStream_t s) {
-        if constexpr (std::is_same<T, double>::value && std::is_same<M, LtvModelT<double, 12, 4>>::value && DIAG) {
-            // all step sizes of a problem at once on the fp64 matrix unit (kernels.hpp); a single stage
+        if constexpr (std::is_same<M, LtvModelT<T, 12, 4>>::value && DIAG) {
+            // all step sizes of a problem at once on the matrix unit (kernels.hpp); a single stage
             static const bool generic = getenv("ILQR_LTV_GENERIC") != nullptr;
             if (!barrier_on(c) && c.n_alphas <= 16 && !generic) {
                 if (!(c.eval_stages & 1)) return hipSuccess;
                 auto p = make_params<T, NX, NU>(c);
-                hipLaunchKernelGGL(ltv12x4_evaluate_mfma_kernel, dim3((c.count + 15) / 16), dim3(1024), 0, s, p);
+                if constexpr (std::is_same<T, double>::value)
+                    hipLaunchKernelGGL(ltv12x4_evaluate_mfma_kernel, dim3((c.count + 15) / 16), dim3(1024), 0, s, p);
+                else
+                    hipLaunchKernelGGL(ltv12x4_evaluate_mfma_f32_kernel, dim3((c.count + 15) / 16), dim3(1024), 0, s, p);
                 return hipGetLastError();
             }
         }
@@ -367,7 +370,7 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
     }
     // number of candidates of the first line-search stage; >= n_alphas: there is no second stage
     static int first_stage_candidates(const HostCtx &c) {
-        if constexpr (std::is_same<T, double>::value && std::is_same<M, LtvModelT<double, 12, 4>>::value && DIAG) {
+        if constexpr (std::is_same<M, LtvModelT<T, 12, 4>>::value && DIAG) {
             static const bool generic = getenv("ILQR_LTV_GENERIC") != nullptr;
             if (!barrier_on(c) && c.n_alphas <= 16 && !generic) return 16;
         }

@@ -925,12 +925,131 @@ __device__ __forceinline__ int ltv12x4_backward_sweep(const Params<double, 12, 4
 
 
 
+// The same sweep in fp32 (v_mfma_f32_16x16x4).  That instruction returns register r of lane
+// (c, g) = M[4 g + r][c] (the fp64 one: M[g + 4 r][c]), so the contraction index of call k in lane
+// group g is 4 g + k, rows 12..15 of a tile live in lane group 3 (all four calls of a product are
+// needed; group 3 supplies zeros), and the last lane group of the D-layout G holds whole columns:
+// lane (c, 3) has Qux[0..3][c] (c < 12) or Quu[0..3][c - 12], so it solves for column c of K on its
+// own.  The rank-4 update K'Qux contracts over lane group 0 and takes four calls.
+typedef float v4f32_ __attribute__((ext_vector_type(4)));
+
+template <bool ASSUME_PD>
+__device__ __forceinline__ int ltv12x4_backward_sweep(const Params<float, 12, 4> &p, float *sh, int slot, int lane, bool &bad) {
+    constexpr int NX = 12, NU = 4;
+    const int c = lane & 15, g = lane >> 4;
+    const int T1 = p.N - 1;
+    const int tile = slot >> 6, ln = slot & 63;
+    const float *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
+    const float *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
+    const float *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
+    float *kp = tile_ptr(p.k, tile, T1 * NU, ln);
+    float *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    const bool isx = c < NX, g3 = g == 3;
+    const int cu = isx ? 0 : c - NX;
+    const float lw = isx ? p.Q2[c * NX + c] : p.R2[cu * NU + cu];
+    bool dpos[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dpos[r] = (4 * g + r == c);
+    auto load_xu = [&](int t) { return isx ? Xt[(size_t)(t * NX + c) * TILE] : Ut[(size_t)(t * NU + cu) * TILE]; };
+    auto load_xr = [&](int t) { return isx ? Rt[(size_t)(t * NX + c) * TILE] : 0.0f; };
+    auto load_F = [&](int t, int kk) { // F[4 g + kk][c] of step t; rows 12..15 are zero
+        const int k = g3 ? 0 : 4 * g + kk;
+        const float v = isx ? p.ltvA[(size_t)t * NX * NX + k * NX + c] : p.ltvB[(size_t)t * NX * NU + k * NU + cu];
+        return g3 ? 0.0f : v;
+    };
+    float vx = isx ? p.Qf2[c * NX + c] * (Xt[(size_t)(T1 * NX + c) * TILE] - Rt[(size_t)(T1 * NX + c) * TILE]) : 0.0f;
+    float Vt[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Vt[r] = (isx && dpos[r]) ? p.Qf2[c * NX + c] : 0.0f;
+    int status = 0;
+    constexpr int PFL = 4;
+    float rxu[PFL], rxr[PFL], rF[PFL][4];
+#pragma unroll
+    for (int s = 0; s < PFL; ++s) {
+        const int ts = T1 - 1 - s > 0 ? T1 - 1 - s : 0;
+        rxu[s] = load_xu(ts);
+        rxr[s] = load_xr(ts);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) rF[s][kk] = load_F(ts, kk);
+    }
+    for (int tb = T1 - 1; tb >= 0; tb -= PFL)
+#pragma unroll
+    for (int s = 0; s < PFL; ++s) {
+        const int t = tb - s;
+        if (t < 0) break;
+        const float xu_c = rxu[s], xr_c = rxr[s];
+        float F[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) F[kk] = rF[s][kk];
+        const int tn = t - PFL > 0 ? t - PFL : 0;
+        rxu[s] = load_xu(tn);
+        rxr[s] = load_xr(tn);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) rF[s][kk] = load_F(tn, kk);
+        // [Qx; Qu] = [lx; lu] + F' Vx
+        float part = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) part = fma_(F[kk], __shfl(vx, (4 * g + kk) & 15), part); // group 3: F is zero there
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        const float qv = fma_(lw, xu_c - xr_c, part);
+        v4f32_ W = {0.f, 0.f, 0.f, 0.f}, TG = {0.f, 0.f, 0.f, 0.f}, DG = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) W = __builtin_amdgcn_mfma_f32_16x16x4f32(Vt[kk] + (dpos[kk] && isx ? p.lm : 0.0f), F[kk], W, 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) TG = __builtin_amdgcn_mfma_f32_16x16x4f32(g3 ? 0.0f : W[kk], F[kk], TG, 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) DG = __builtin_amdgcn_mfma_f32_16x16x4f32(F[kk], g3 ? 0.0f : W[kk], DG, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            TG[r] += dpos[r] ? lw : 0.0f;
+            DG[r] += dpos[r] ? lw : 0.0f;
+        }
+        __syncthreads();
+        if (g3 && !isx) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sh[r * 4 + cu] = DG[r]; // Quu[r][cu]
+            sh[16 + cu] = qv;                                   // Qu[cu]
+        }
+        __syncthreads();
+        float Quu[NU][NU], rhs[NU][2], Qu[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) Quu[i][j] = sh[i * 4 + j];
+            Qu[i] = sh[16 + i];
+            rhs[i][0] = -Qu[i];
+            rhs[i][1] = -DG[i]; // lane (c, 3), c < 12: -Qux[i][c]
+        }
+        status |= solve_quu<float, NU, 2, ASSUME_PD>(Quu, rhs, bad);
+        if (g3 && isx) {
+#pragma unroll
+            for (int q = 0; q < NU; ++q) Kp[(size_t)((t * NU + q) * NX + c) * TILE] = rhs[q][1];
+        }
+        if (g3 && !isx) kp[(size_t)(t * NU + cu) * TILE] = cu == 0 ? rhs[0][0] : cu == 1 ? rhs[1][0] : cu == 2 ? rhs[2][0] : rhs[3][0];
+        float nvx = qv;
+#pragma unroll
+        for (int q = 0; q < NU; ++q) nvx = fma_(rhs[q][1], Qu[q], nvx);
+        vx = isx ? __shfl(nvx, 48 + c) : 0.0f;
+        // Vxx = Qxx + K' Qux: operands on lane group 0, fetched from lane group 3
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float qx = __shfl(DG[kk], 48 + c), kx = __shfl(rhs[kk][1], 48 + c);
+            const bool on = g == 0 && isx;
+            TG = __builtin_amdgcn_mfma_f32_16x16x4f32(on ? qx : 0.0f, on ? kx : 0.0f, TG, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Vt[r] = (isx && !g3) ? TG[r] : 0.0f;
+    }
+    return status;
+}
+
 // REDO = false: every selected problem, branch-free solve; a problem whose Quu was not positive
 // definite somewhere is flagged in p.redo.  REDO = true (a second, normally idle launch): only the
 // flagged problems, with the pivoted-LU fallback.  Two kernels, so that the fallback's registers
 // do not cost the main kernel its occupancy.
-template <bool REDO> __global__ __launch_bounds__(64) void ltv12x4_backward_mfma_kernel(Params<double, 12, 4> p) {
-    __shared__ double sh[80];
+template <typename T, bool REDO> __global__ __launch_bounds__(64) void ltv12x4_backward_mfma_kernel(Params<T, 12, 4> p) {
+    __shared__ T sh[80];
     const int lane = threadIdx.x;
     const int nsl = slot_count(p);
     // 64 consecutive workgroups of one XCD (workgroups are dealt to the 8 XCDs in turn) take the
@@ -1616,6 +1735,110 @@ static __global__ __launch_bounds__(1024) void ltv12x4_evaluate_mfma_kernel(Para
     if (act && lane == 0) {
         p.alpha_idx[o] = best;
         p.Jtry[o] = best < 0 ? 0.0 : best_cost;
+        p.slow_trig[o] = p.slow_trig[o] & 6;
+    }
+}
+
+// fp32 variant (v_mfma_f32_16x16x4, register r of lane (c, g) = M[4 g + r][c]): lane groups 0..2
+// carry the states 4 g + r of candidate c, lane group 3 its four inputs; the feedback K dX comes
+// out in lane group 0 and is passed to lane group 3.
+static __global__ __launch_bounds__(1024) void ltv12x4_evaluate_mfma_f32_kernel(Params<float, 12, 4> p) {
+    constexpr int NX = 12, NU = 4;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const bool g3 = g == 3;
+    const int nsl = slot_count(p);
+    const int slot_raw = blockIdx.x * 16 + (threadIdx.x >> 6);
+    const int slot = slot_raw < nsl ? slot_raw : (nsl > 0 ? nsl - 1 : 0);
+    const int o = orig_of(p, slot);
+    const bool act = slot_raw < nsl && p.converged[o] == 0;
+    if (!__syncthreads_or(act)) return;
+    const int T1 = p.N - 1;
+    const int tile = slot >> 6, ln = slot & 63;
+    const float *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
+    const float *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
+    const float *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
+    const float *kp = tile_ptr(p.k, tile, T1 * NU, ln);
+    const float *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    const float Jcur = p.J[o];
+    const float alpha = pow2_neg<float>(c);
+    float w[4], wf[4], lo[4], hi[4]; // stage / terminal weight of this lane's four components, input box
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = g3 ? 0 : 4 * g + r;
+        w[r] = g3 ? p.R[r * NU + r] : p.Q[j * NX + j];
+        wf[r] = g3 ? 0.0f : p.Qf[j * NX + j];
+        lo[r] = p.lo[r];
+        hi[r] = p.hi[r];
+    }
+    struct Row {
+        float a[4], b[4], Kop[4], Fop[4]; // a: x_prev (groups 0..2) / u_prev (group 3); b: xref / k
+    };
+    auto load_row = [&](int t, Row &r) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = g3 ? 0 : 4 * g + q;
+            r.a[q] = g3 ? Ut[(size_t)(t * NU + q) * TILE] : Xt[(size_t)(t * NX + j) * TILE];
+            r.b[q] = g3 ? kp[(size_t)(t * NU + q) * TILE] : Rt[(size_t)(t * NX + j) * TILE];
+            const float kv = Kp[(size_t)((t * NU + (c & 3)) * NX + j) * TILE];                    // K[c][4g + q]
+            r.Kop[q] = (c < NU && !g3) ? kv : 0.0f;
+            const int cc = c < NX ? c : 0;
+            const float fv = g3 ? p.ltvB[(size_t)t * NX * NU + cc * NU + q] : p.ltvA[(size_t)t * NX * NX + cc * NX + j];
+            r.Fop[q] = c < NX ? fv : 0.0f;                                                         // F[c][4g + q]
+        }
+    };
+    float z[4], cost = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z[r] = g3 ? 0.0f : Xt[(size_t)(4 * g + r) * TILE];
+    Row nxt;
+    load_row(0, nxt);
+    for (int t = 0; t < T1; ++t) {
+        if ((t & (LTV_SYNC_EVERY - 1)) == 0) __syncthreads();
+        if (!act) continue; // wave-uniform
+        const Row r = nxt;
+        load_row(t + 1 < T1 ? t + 1 : t, nxt);
+        float dx[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dx[q] = g3 ? 0.0f : z[q] - r.a[q];
+        v4f32_ KD = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) KD = __builtin_amdgcn_mfma_f32_16x16x4f32(r.Kop[q], dx[q], KD, 0, 0, 0);
+        float val[4]; // what the stage cost squares: x - xref (groups 0..2), the new input (group 3)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float fb = __shfl(KD[q], c); // (K dX)[q][c] from lane group 0
+            float v = fma_(alpha, r.b[q], r.a[q]) + fb;
+            v = (lo[q] > v) ? lo[q] : v;
+            v = (hi[q] < v) ? hi[q] : v;
+            val[q] = g3 ? v : z[q] - r.b[q];
+            z[q] = g3 ? v : z[q];
+        }
+        float stage = (w[0] * val[0]) * val[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) stage = fma_(w[q] * val[q], val[q], stage);
+        cost += stage;
+        v4f32_ Xn = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Xn = __builtin_amdgcn_mfma_f32_16x16x4f32(r.Fop[q], z[q], Xn, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) z[q] = g3 ? 0.0f : Xn[q];
+    }
+    {
+        float term = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float e = g3 ? 0.0f : z[q] - Rt[(size_t)(T1 * NX + (g3 ? 0 : 4 * g + q)) * TILE];
+            term = fma_(wf[q] * e, e, term);
+        }
+        cost += term;
+    }
+    cost += __shfl_xor(cost, 16);
+    cost += __shfl_xor(cost, 32);
+    const unsigned long long win = __ballot(g == 0 && c < p.n_alphas && cost < Jcur);
+    const int best = win ? __ffsll((long long)win) - 1 : -1;
+    const float best_cost = __shfl(cost, best < 0 ? 0 : best);
+    if (act && lane == 0) {
+        p.alpha_idx[o] = best;
+        p.Jtry[o] = best < 0 ? 0.0f : best_cost;
         p.slow_trig[o] = p.slow_trig[o] & 6;
     }
 }

@@ -595,8 +595,16 @@ def test_ltv12x4_fp32_mode(ilqr_cls, oracle):
     p = problems.ltv_batch(B, N)
     opt = ilqr_cls(s, p["target_states"], s.dt, history=True, dtype=np.float32)
     opt.inputs, opt.states = p["init_inputs"].copy(), p["init_states"].copy()
-    opt()
     d = oracle.make_desc(s, N)
+    # first backward pass of the fp32 matrix-unit kernel against the fp64 oracle
+    dev = opt.upload()
+    dev.initial_cost()
+    dev.backward()
+    for b in (0, 7):
+        Ko, ko, rc = oracle.backward(d, np.ascontiguousarray(p["target_states"][b]), p["init_states"][b].copy(),
+                                     p["init_inputs"][b].copy())
+        assert nrm(dev.download_K()[b], Ko) <= 5e-4 and nrm(dev.download_k()[b][:, :, 0], ko) <= 5e-4
+    opt()
     r = oracle.solve_batch(d, p["target_states"], p["init_states"].copy(), p["init_inputs"].copy())
     assert np.abs(opt.cost_history[:, 0] - r["hist_cost"][:, 0]).max() <= 1e-4 * np.abs(r["hist_cost"][:, 0]).max()
     assert np.abs(opt.min_cost - r["min_cost"]).max() <= 2e-3 * np.abs(r["min_cost"]).max()
