@@ -7,7 +7,7 @@
 
 One *step* = one complete batched solve (``iterative_LQR.__call__``: initial cost, then up to
 30 backward/forward iterations per problem until its ``converge`` flag) of B Car problems with
-horizon N=200 in fp64, the configuration BASELINE.json's metric is quoted on.  Inputs are
+horizon N=200 in fp64, the configuration the headline metric is quoted on.  Inputs are
 resident in HBM when the timed region starts; every step restores the initial guess with a
 device-to-device copy (inside the timed region) and solves again.  With N GPUs every rank
 solves its own B problems (weak scaling, no communication on the solve path); the reported

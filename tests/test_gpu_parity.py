@@ -463,7 +463,7 @@ def test_barrier_mode_matches_oracle(oracle):
 
 # --------------------------------------------------------------------------- full size
 def test_full_size_batch_properties(ilqr_cls, oracle):
-    """BASELINE configuration (B=65536, N=200, Car, fp64), checked through size-independent
+    """The benchmark configuration (B=65536, N=200, Car, fp64), checked through size-independent
     properties plus a sampled full comparison against the oracle."""
     from ilqr_amd import problems
     B, N = 65536, 200
