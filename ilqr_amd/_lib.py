@@ -8,6 +8,7 @@ import ctypes as C
 import os
 
 MAX_N, MAX_M = 12, 4
+MODEL_USER_BASE = 16
 F64, F32 = 0, 1
 CONSTR_NONE, CONSTR_BOXQP, CONSTR_BARRIER = 0, 1, 2
 STATUS_NONPD, STATUS_SINGULAR, STATUS_NONFINITE = 1, 2, 4
@@ -72,6 +73,10 @@ _SIGNATURES = {
     "ilqr_active_count": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "ilqr_to_tiled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ilqr_from_tiled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "ilqr_load_model": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
+    "ilqr_model_dims": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "ilqr_model_probe": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "ilqr_strerror": (C.c_char_p, [C.c_int]),
     "ilqr_last_hip_error": (C.c_int, []),
     "ilqr_desc_size": (C.c_int32, []),

@@ -46,12 +46,22 @@ class DeviceProblem:
         torch = _torch()
         if not torch.cuda.is_available():
             raise _lib.IlqrError("no GPU visible: the batched iLQR solve runs on the HIP device only")
-        if getattr(system, "device_model_id", None) is None:
-            raise _lib.IlqrError(
-                f"{type(system).__name__} has no device dynamics; use Car, CarAcceleration, DubinsCar or LTVSystem")
         self.lib = _lib.lib()
         self.device = torch.device(device if device is not None else "cuda")
         self.np_dtype = _np_dtype(dtype)
+        if hasattr(system, "device_model"):
+            # dynamics compiled at run time (systems.DeviceSystem): built for this element type and
+            # for diagonal or dense cost weights, whichever the system has
+            diag = all(np.count_nonzero(W - np.diag(np.diagonal(W))) == 0
+                       for W in (np.asarray(system.Q, dtype=float), np.asarray(system.R, dtype=float),
+                                 np.asarray(system.Q_f, dtype=float)))
+            model_id = system.device_model(self.np_dtype, diag)
+        else:
+            model_id = getattr(system, "device_model_id", None)
+        if model_id is None:
+            raise _lib.IlqrError(
+                f"{type(system).__name__} has no device dynamics; use Car, CarAcceleration, DubinsCar, LTVSystem "
+                "or derive the model from systems.DeviceSystem")
         self.t_dtype = torch.float64 if self.np_dtype == np.float64 else torch.float32
         self.B, self.N = int(B), int(N)
         self.n, self.m = int(system.state_size), int(system.control_size)
@@ -60,7 +70,7 @@ class DeviceProblem:
 
         d = _lib.Desc()
         d.B, d.N, d.n, d.m = B, N, n, m
-        d.model = int(system.device_model_id)
+        d.model = int(model_id)
         d.dtype = _lib.F64 if self.np_dtype == np.float64 else _lib.F32
         d.control_limited = int(bool(system.control_limited))
         d.constraint_mode = int(constraint_mode)
@@ -116,6 +126,10 @@ class DeviceProblem:
                 self.centers = torch.zeros(Bp * N * 2, dtype=td, device=dev)
                 self.radius = torch.ones(Bp * N, dtype=td, device=dev)
             self.ltv_A = self.ltv_B = None
+            if getattr(system, "device_tables", None) is not None:  # parameter tables of a run-time compiled model
+                ta, tb = system.device_tables
+                self.ltv_A = torch.from_numpy(np.ascontiguousarray(ta, dtype=self.np_dtype)).to(dev)
+                self.ltv_B = torch.from_numpy(np.ascontiguousarray(tb, dtype=self.np_dtype)).to(dev)
             if d.model == 3:  # table-driven LTV: the tables are shared by the whole batch
                 A = np.ascontiguousarray(system.A, dtype=self.np_dtype)
                 Bm = np.ascontiguousarray(system.B, dtype=self.np_dtype)

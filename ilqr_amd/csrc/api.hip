@@ -6,7 +6,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
+#include <mutex>
 #include <new>
+#include <string>
 
 using namespace ilqr;
 
@@ -41,6 +44,47 @@ struct ilqr_handle {
 };
 
 static thread_local int g_last_hip_error = 0;
+
+// Model libraries loaded at run time (ilqr_load_model).  Entries are never removed: handles keep
+// pointers into the launch tables of the library they were created from.
+namespace {
+struct LoadedModel {
+    std::string path;
+    PluginInfo info;
+};
+constexpr int MAX_LOADED_MODELS = 256;
+std::mutex g_models_mutex;
+LoadedModel *g_models[MAX_LOADED_MODELS];
+int g_n_models = 0;
+
+const LoadedModel *loaded_model(int model_id) {
+    std::lock_guard<std::mutex> lock(g_models_mutex);
+    const int i = model_id - ILQR_MODEL_USER_BASE;
+    return (i >= 0 && i < g_n_models) ? g_models[i] : nullptr;
+}
+
+// n, m and the launch table of a model id; false if the id is unknown
+bool model_lookup(int model, int dtype, bool diag, int &n, int &m, bool &has_barrier, const ModelOps *&ops) {
+    has_barrier = false;
+    switch (model) {
+    case ILQR_MODEL_CAR: n = 4; m = 2; has_barrier = true; ops = ops_car(dtype, diag); return true;
+    case ILQR_MODEL_CARACC: n = 5; m = 2; ops = ops_caracc(dtype, diag); return true;
+    case ILQR_MODEL_DUBINS: n = 3; m = 2; ops = ops_dubins(dtype, diag); return true;
+    case ILQR_MODEL_LTV:
+        // table-driven x+ = A_t x + B_t u; built for n = 12, m = 4 with diagonal cost weights
+        n = 12; m = 4; ops = dtype == ILQR_F64 ? ops_ltv12x4_f64(diag) : ops_ltv12x4_f32(diag);
+        return true;
+    default: break;
+    }
+    const LoadedModel *lm = loaded_model(model);
+    if (!lm) return false;
+    n = lm->info.n;
+    m = lm->info.m;
+    has_barrier = lm->info.has_barrier != 0;
+    ops = lm->info.ops(dtype, diag);
+    return true;
+}
+} // namespace
 
 static int hip_rc(hipError_t e) {
     if (e == hipSuccess) return ILQR_OK;
@@ -202,23 +246,15 @@ int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
     if (!(d.dt == d.dt)) return ILQR_ERR_INVALID;
     int want_n = 0, want_m = 0;
     const ModelOps *ops = nullptr;
+    bool has_barrier = false;
     bool diag = is_diag(d.Q, d.n) && is_diag(d.Qf, d.n) && is_diag(d.R, d.m);
-    switch (d.model) {
-    case ILQR_MODEL_CAR: want_n = 4; want_m = 2; ops = ops_car(d.dtype, diag); break;
-    case ILQR_MODEL_CARACC: want_n = 5; want_m = 2; ops = ops_caracc(d.dtype, diag); break;
-    case ILQR_MODEL_DUBINS: want_n = 3; want_m = 2; ops = ops_dubins(d.dtype, diag); break;
-    case ILQR_MODEL_LTV:
-        // table-driven x+ = A_t x + B_t u; built for n = 12, m = 4 with diagonal cost weights
-        if (d.n != 12 || d.m != 4) return ILQR_ERR_UNSUPPORTED;
-        want_n = 12; want_m = 4; ops = d.dtype == ILQR_F64 ? ops_ltv12x4_f64(diag) : ops_ltv12x4_f32(diag);
-        break;
-    default: return ILQR_ERR_UNSUPPORTED;
-    }
+    if (!model_lookup(d.model, d.dtype, diag, want_n, want_m, has_barrier, ops)) return ILQR_ERR_UNSUPPORTED;
+    if (d.model == ILQR_MODEL_LTV && (d.n != 12 || d.m != 4)) return ILQR_ERR_UNSUPPORTED;
     if (d.n != want_n || d.m != want_m) return ILQR_ERR_INVALID;
     if (!ops) return ILQR_ERR_UNSUPPORTED;
     if ((d.constraint_mode & ILQR_CONSTR_BARRIER)) {
         // the constraint functions are written for the Car state layout (constraints.py:12)
-        if (d.model != ILQR_MODEL_CAR) return ILQR_ERR_UNSUPPORTED;
+        if (!has_barrier) return ILQR_ERR_UNSUPPORTED;
         if (!(d.barrier_mu >= 0.0) || !(d.barrier_delta > 0.0)) return ILQR_ERR_INVALID;
     }
     if ((d.constraint_mode & ILQR_CONSTR_BOXQP) || d.control_limited)
@@ -321,6 +357,7 @@ int ilqr_bind(ilqr_handle *h, const ilqr_buffers *b) {
     if (!b->X || !b->U || !b->Xref || !b->K || !b->k || !b->J || !b->converged || !b->iters || !b->alpha_idx || !b->work)
         return ILQR_ERR_NOT_BOUND;
     if ((h->ctx.d.constraint_mode & ILQR_CONSTR_BARRIER) && (!b->centers || !b->radius)) return ILQR_ERR_NOT_BOUND;
+    // models loaded at run time may or may not read the tables: binding them is their caller's duty
     if (h->ctx.d.model == ILQR_MODEL_LTV && (!b->ltv_A || !b->ltv_B)) return ILQR_ERR_NOT_BOUND;
     if ((b->hist_cost || b->hist_alpha) && b->hist_capacity <= 0) return ILQR_ERR_INVALID;
     h->ctx.b = *b;
@@ -557,6 +594,65 @@ int ilqr_to_tiled(const void *aos, void *tiled, int32_t B, int32_t rows, int32_t
 
 int ilqr_from_tiled(const void *tiled, void *aos, int32_t B, int32_t rows, int32_t elem_bytes, void *stream) {
     return relayout<false>(tiled, aos, B, rows, elem_bytes, stream);
+}
+
+int ilqr_load_model(const char *path, int32_t *model_id) {
+    if (!path || !model_id) return ILQR_ERR_INVALID;
+    *model_id = -1;
+    std::lock_guard<std::mutex> lock(g_models_mutex);
+    for (int i = 0; i < g_n_models; ++i)
+        if (g_models[i]->path == path) {
+            *model_id = ILQR_MODEL_USER_BASE + i;
+            return ILQR_OK;
+        }
+    if (g_n_models >= MAX_LOADED_MODELS) return ILQR_ERR_UNSUPPORTED;
+    void *dl = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!dl) return ILQR_ERR_INVALID;
+    typedef int (*query_fn)(PluginInfo *);
+    query_fn query = (query_fn)dlsym(dl, "ilqr_model_plugin");
+    PluginInfo info;
+    std::memset(&info, 0, sizeof(info));
+    if (!query || query(&info) != 0 || info.abi != plugin_abi() || !info.ops || info.n <= 0 || info.n > ILQR_MAX_N || info.m <= 0 ||
+        info.m > ILQR_MAX_M) {
+        dlclose(dl);
+        return query && info.abi != plugin_abi() ? ILQR_ERR_UNSUPPORTED : ILQR_ERR_INVALID;
+    }
+    LoadedModel *lm = new (std::nothrow) LoadedModel();
+    if (!lm) {
+        dlclose(dl);
+        return ILQR_ERR_INVALID;
+    }
+    lm->path = path;
+    lm->info = info;
+    g_models[g_n_models] = lm;
+    *model_id = ILQR_MODEL_USER_BASE + g_n_models;
+    ++g_n_models;
+    return ILQR_OK;
+}
+
+int ilqr_model_dims(int32_t model, int32_t *n, int32_t *m) {
+    if (!n || !m) return ILQR_ERR_INVALID;
+    int nn = 0, mm = 0;
+    bool hb = false;
+    const ModelOps *ops = nullptr;
+    if (!model_lookup(model, ILQR_F64, true, nn, mm, hb, ops)) return ILQR_ERR_UNSUPPORTED;
+    *n = nn;
+    *m = mm;
+    return ILQR_OK;
+}
+
+int ilqr_model_probe(int32_t model, int32_t dtype, double dt, int32_t t, const void *params_a, const void *params_b, const void *x,
+                     const void *u, void *x_next, void *fx, void *fu, int32_t count, void *stream) {
+    if (!x || !u || !x_next || !fx || !fu || count <= 0 || t < 0) return ILQR_ERR_INVALID;
+    if (dtype != ILQR_F64 && dtype != ILQR_F32) return ILQR_ERR_INVALID;
+    int n = 0, m = 0;
+    bool hb = false;
+    const ModelOps *ops = nullptr;
+    if (!model_lookup(model, dtype, true, n, m, hb, ops)) return ILQR_ERR_UNSUPPORTED;
+    if (!ops && !model_lookup(model, dtype, false, n, m, hb, ops)) return ILQR_ERR_UNSUPPORTED;
+    if (!ops) return ILQR_ERR_UNSUPPORTED;
+    if (model == ILQR_MODEL_LTV && (!params_a || !params_b)) return ILQR_ERR_NOT_BOUND;
+    return hip_rc(ops->probe(dt, params_a, params_b, x, u, x_next, fx, fu, count, t, (hipStream_t)stream));
 }
 
 const char *ilqr_strerror(int code) {

@@ -91,9 +91,27 @@ static inline WorkLayout work_layout(const ilqr_desc &d, bool compaction) {
 }
 
 typedef hipError_t (*launch_fn)(const HostCtx &, int it, hipStream_t);
+// the dynamics at `count` given points (model_probe_kernel); element type = the table's
+typedef hipError_t (*probe_fn)(double dt, const void *ltvA, const void *ltvB, const void *x, const void *u, void *xn, void *fx, void *fu,
+                               int count, int t, hipStream_t);
 struct ModelOps {
     launch_fn cost, backward, evaluate, commit;
+    probe_fn probe;
 };
+
+// What a separately compiled model library (ilqr_load_model) hands to this one.  `abi` must equal
+// plugin_abi() of the loading library: both sides are compiled from the same headers, and the
+// launch tables exchange HostCtx by reference.
+struct PluginInfo {
+    int32_t abi;
+    int32_t n, m;
+    int32_t has_barrier; // the state starts with (px, py, v): the barrier terms of constraints.py:20-26 apply
+    const ModelOps *(*ops)(int dtype, bool diag);
+};
+constexpr int32_t PLUGIN_ABI_VERSION = 1;
+static inline int32_t plugin_abi() {
+    return (int32_t)(PLUGIN_ABI_VERSION * 1000003u + sizeof(HostCtx) * 31u + sizeof(ilqr_desc) * 7u + sizeof(ilqr_buffers));
+}
 
 // one table per translation unit (ops_*.hip); nullptr if the combination is not built
 const ModelOps *ops_car(int dtype, bool diag);
@@ -403,8 +421,18 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
     static hipError_t commit(const HostCtx &c, int it, hipStream_t s) {
         return c.reroll ? commit_all<true>(c, it, s) : commit_all<false>(c, it, s);
     }
+    static hipError_t probe(double dt, const void *ltvA, const void *ltvB, const void *x, const void *u, void *xn, void *fx, void *fu,
+                            int count, int t, hipStream_t s) {
+        Params<T, NX, NU> p = {};
+        p.dt = (T)dt;
+        p.ltvA = (const T *)ltvA;
+        p.ltvB = (const T *)ltvB;
+        hipLaunchKernelGGL((model_probe_kernel<T, M>), dim3((count + 63) / 64), dim3(64), 0, s, p, (const T *)x, (const T *)u, (T *)xn,
+                           (T *)fx, (T *)fu, count, t);
+        return hipGetLastError();
+    }
     static const ModelOps *table() {
-        static const ModelOps ops = {&cost, &backward, &evaluate, &commit};
+        static const ModelOps ops = {&cost, &backward, &evaluate, &commit, &probe};
         return &ops;
     }
 };

@@ -2107,6 +2107,36 @@ template <typename T> __global__ __launch_bounds__(64) void repack_move_kernel(R
     }
 }
 
+// ---------------------------------------------------------------- model probe
+// The device dynamics evaluated at given points, one lane per point, reference layout in and
+// out: x [count][NX], u [count][NU] -> xn [count][NX] (model_f, systems.py:33-40),
+// fx [count][NX][NX] (compute_df_dx, systems.py:42-50), fu [count][NX][NU] (compute_df_du,
+// systems.py:52-57), all at time step t.  Lets a caller check a device model against its host
+// statement or against finite differences before solving with it.  Not on the solve path.
+template <typename T, class M>
+__global__ __launch_bounds__(64) void model_probe_kernel(Params<T, M::NX, M::NU> p, const T *x, const T *u, T *xn, T *fx, T *fu, int count,
+                                                         int t) {
+    constexpr int NX = M::NX, NU = M::NU;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= count) return;
+    T xl[NX], ul[NU], xo[NX], fxl[NX][NX], ful[NX][NU];
+    for (int i = 0; i < NX; ++i) xl[i] = x[(size_t)b * NX + i];
+    for (int i = 0; i < NU; ++i) ul[i] = u[(size_t)b * NU + i];
+    for (int i = 0; i < NX; ++i) {
+        for (int j = 0; j < NX; ++j) fxl[i][j] = M::fx_one(i, j) ? T(1) : T(0);
+        for (int j = 0; j < NU; ++j) ful[i][j] = T(0);
+    }
+    bool bad = false;
+    M::template step<false>(p, t, xl, ul, xo, bad);
+    M::template jac<false>(p, t, xl, ul, fxl, ful, bad);
+    for (int i = 0; i < NX; ++i) {
+        xn[(size_t)b * NX + i] = xo[i];
+        // entries a model declares structurally zero are never read by the solver kernels
+        for (int j = 0; j < NX; ++j) fx[((size_t)b * NX + i) * NX + j] = M::fx_nz(i, j) ? fxl[i][j] : T(0);
+        for (int j = 0; j < NU; ++j) fu[((size_t)b * NX + i) * NU + j] = M::fu_nz(i, j) ? ful[i][j] : T(0);
+    }
+}
+
 // ---------------------------------------------------------------- receding-horizon warm start
 // One lane per problem: the trajectory is moved `shift` steps towards the start (the last
 // state/input is repeated at the end), optionally the first state is replaced by a new initial

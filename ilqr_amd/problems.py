@@ -274,3 +274,58 @@ def ltv_batch(B, N=500, n=12, m=4, seed0=777, first=0):
     st = np.zeros((B, N, n))
     st[:, 0] = x0
     return {"target_states": tg, "init_inputs": np.zeros((B, N - 1, m)), "x0": x0, "init_states": st}
+
+
+# ---- problems for the models of ilqr_amd/user_models.py (no reference demo exists for them;
+# the constructions follow the pattern of ilqr_demo.py:10-45: a smooth reference motion, noise
+# on the targets, finite differences of the noisy targets as the initial inputs) ----------
+# every state component carries weight: with an unweighted steering angle the Riccati recursion of
+# this model amplifies last-bit differences by many orders of magnitude per iteration, which makes
+# a problem useless as a parity fixture
+BICYCLE_Q = np.diag([10.0, 10.0, 100.0, 100.0, 100.0])
+BICYCLE_R = np.diag([100.0, 100.0])
+BICYCLE_LIMITS = ([-3.0, -0.5], [3.0, 0.5])
+PENDULUM_Q = np.diag([100.0, 1.0])
+PENDULUM_R = np.diag([0.1])
+PENDULUM_LIMITS = ([-20.0], [20.0])
+
+
+def bicycle_batch(B, N=150, seed0=4321, first=0, dt=0.1, wheelbase=2.5):
+    """``B`` kinematic-bicycle tracking problems; problem ``b`` depends on ``seed0 + first + b`` only."""
+    tg = np.zeros((B, N, 5))
+    ui = np.zeros((B, N - 1, 2))
+    x0 = np.zeros((B, 5))
+    for b in range(B):
+        rng = np.random.Generator(np.random.PCG64(seed0 + first + b))
+        v = rng.uniform(3.0, 8.0) + rng.uniform(0.2, 1.0) * dt * np.arange(N)
+        delta = rng.uniform(-0.2, 0.2) + 0.1 * np.sin(rng.uniform(0.5, 1.5) * dt * np.arange(N))
+        theta = rng.uniform(-np.pi, np.pi) + np.concatenate([[0.0], np.cumsum(v[:-1] * np.tan(delta[:-1]) / wheelbase * dt)])
+        px = rng.uniform(-5, 5) + np.concatenate([[0.0], np.cumsum(v[:-1] * np.cos(theta[:-1]) * dt)])
+        py = rng.uniform(-5, 5) + np.concatenate([[0.0], np.cumsum(v[:-1] * np.sin(theta[:-1]) * dt)])
+        ref = np.stack([px, py, theta, v, delta], axis=-1)
+        noisy = ref.copy()
+        noisy[1:, 0:2] += rng.uniform(0.0, 1.0, size=(N - 1, 2))
+        noisy[1:, 2] += rng.uniform(0.0, 0.1, size=N - 1)
+        tg[b] = noisy
+        x0[b] = ref[0]
+        ui[b, :, 0] = np.diff(noisy[:, 3]) / dt
+        ui[b, :, 1] = np.diff(noisy[:, 4]) / dt
+    init_states = np.zeros_like(tg)
+    init_states[:, 0] = x0
+    return dict(target_states=tg, init_inputs=ui, x0=x0, init_states=init_states)
+
+
+def pendulum_batch(B, N=120, seed0=987, first=0):
+    """``B`` pendulum swing problems: reach the upright position from a random hanging state."""
+    tg = np.zeros((B, N, 2))
+    x0 = np.zeros((B, 2))
+    for b in range(B):
+        rng = np.random.Generator(np.random.PCG64(seed0 + first + b))
+        x0[b] = [rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5)]
+        ramp = np.minimum(1.0, np.arange(N) / (0.6 * N))
+        tg[b, :, 0] = x0[b, 0] + (np.pi - x0[b, 0]) * ramp
+        tg[b, 1:, 1] = np.diff(tg[b, :, 0]) / 0.05
+    ui = np.zeros((B, N - 1, 1))
+    init_states = np.zeros_like(tg)
+    init_states[:, 0] = x0
+    return dict(target_states=tg, init_inputs=ui, x0=x0, init_states=init_states)

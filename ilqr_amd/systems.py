@@ -12,6 +12,10 @@ and are never called by the GPU solve.
 ``LTVSystem`` is an extension with no reference counterpart: a table-driven
 time-varying linear model ``x+ = A_t x + B_t u`` (``model_f(x, u)`` of the
 reference has no time argument, so such a system cannot be expressed there).
+
+``DeviceSystem`` is the base class for any other model: a subclass keeps the
+reference's numpy methods and adds the same dynamics as a device-code snippet,
+which is compiled on first use (``ilqr_amd/jit.py``).
 """
 import numpy as np
 
@@ -175,3 +179,104 @@ class LTVSystem(System):
 
     def compute_df_du(self, x, u, t=0):
         return self.B[t].copy()
+
+
+class DeviceSystem(System):
+    """A user-defined model for the GPU solve.
+
+    The reference solver works with any ``System`` subclass because it calls
+    ``model_f`` / ``compute_df_dx`` / ``compute_df_du`` in Python at every time step
+    (``ilqr.py:62``, ``:87-88``).  The kernels cannot, so a subclass states the model twice:
+    the numpy methods exactly as for the reference (they stay the host-side definition and
+    are what ``check_device_model`` compares against), and two device snippets::
+
+        class Pendulum(DeviceSystem):
+            device_step = "T s, c; sincos_<FAST>(x[0], s, c, bad);" \
+                          "xn[0] = fma_(x[1], dt, x[0]); xn[1] = fma_(u[0] - T(9.81) * s, dt, x[1]);"
+            device_jac = "T s, c; sincos_<FAST>(x[0], s, c, bad);" \
+                         "fx[0][1] = dt; fx[1][0] = (T(-9.81) * c) * dt; fu[1][0] = dt;"
+            fx_pattern = [[2, 1], [1, 2]]      # 0 = always zero, 1 = non-zero, 2 = always one
+            fu_pattern = [[0], [1]]
+
+    ``ilqr_amd/jit.py`` documents the names a snippet sees.  Without patterns every Jacobian
+    entry is treated as non-zero (correct, slower); with them the Riccati code skips the
+    structural zeros at compile time, as it does for the built-in models.  ``device_tables``
+    may hold two arrays shared by the whole batch that the snippets read as ``par_a`` /
+    ``par_b`` (per-problem parameters are better carried as extra state components with
+    identity dynamics and zero cost weight).
+    """
+
+    device_step = None
+    device_jac = None
+    fx_pattern = None
+    fu_pattern = None
+    device_has_barrier = False   # state starts with (px, py, v): constraints.py:20-26 apply
+    device_tables = None
+
+    def device_model(self, dtype=np.float64, diag=True, verbose=False):
+        """Compile (once) and register the device dynamics; returns the model id."""
+        from . import jit
+        if self.device_step is None or self.device_jac is None:
+            raise ValueError(f"{type(self).__name__}: device_step and device_jac must be set")
+        variant = ("f64" if np.dtype(dtype) == np.float64 else "f32", bool(diag))
+        cache = self.__dict__.setdefault("_device_models", {})
+        key = (variant, self.device_step, self.device_jac)
+        if key not in cache:
+            src = jit.model_source(self.state_size, self.control_size, self.device_step, self.device_jac,
+                                   self.fx_pattern, self.fu_pattern, self.device_has_barrier, variants=(variant,))
+            cache[key] = jit.load_model(jit.build_model(src, verbose=verbose))
+        return cache[key]
+
+    def check_device_model(self, x, u, dtype=np.float64, device=None, t=0):
+        """Evaluate the device snippets at the points ``x (P, n)``, ``u (P, m)`` and return the
+        largest absolute differences to ``model_f``, ``compute_df_dx`` and ``compute_df_du``
+        (called point by point, as the reference solver calls them)."""
+        model = self.device_model(dtype, True)
+        xn, fx, fu = probe_model(model, self.dt, x, u, dtype=dtype, device=device, t=t, tables=self.device_tables)
+        x, u = np.atleast_2d(np.asarray(x, dtype=float)), np.atleast_2d(np.asarray(u, dtype=float))
+        ef = max(np.abs(xn[i] - np.asarray(self.model_f(x[i], u[i]), dtype=float)).max() for i in range(len(x)))
+        ex = max(np.abs(fx[i] - np.asarray(self.compute_df_dx(x[i], u[i]), dtype=float)).max() for i in range(len(x)))
+        eu = max(np.abs(fu[i] - np.asarray(self.compute_df_du(x[i], u[i]), dtype=float)).max() for i in range(len(x)))
+        return ef, ex, eu
+
+
+def probe_model(model_id, dt, x, u, dtype=np.float64, device=None, t=0, tables=None):
+    """Device dynamics of ``model_id`` at the points ``x (P, n)``, ``u (P, m)``:
+    returns ``(x_next (P, n), fx (P, n, n), fu (P, n, m))`` as float64 numpy arrays
+    (``ilqr_model_probe`` of the C ABI)."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    if not torch.cuda.is_available():
+        raise _lib.IlqrError("no GPU visible: the device dynamics can only be evaluated on the HIP device")
+    lib = _lib.lib()
+    npd = np.dtype(dtype)
+    td = torch.float64 if npd == np.float64 else torch.float32
+    dev = torch.device(device if device is not None else "cuda")
+    n, m = C.c_int32(0), C.c_int32(0)
+    _lib.check(lib.ilqr_model_dims(int(model_id), C.byref(n), C.byref(m)), "ilqr_model_dims")
+    n, m = n.value, m.value
+    x = np.ascontiguousarray(np.atleast_2d(np.asarray(x, dtype=npd)))
+    u = np.ascontiguousarray(np.atleast_2d(np.asarray(u, dtype=npd)))
+    P = x.shape[0]
+    if x.shape != (P, n) or u.shape != (P, m):
+        raise ValueError(f"x must be (P, {n}) and u (P, {m})")
+    with torch.cuda.device(dev):
+        xd, ud = torch.from_numpy(x).to(dev), torch.from_numpy(u).to(dev)
+        xn = torch.zeros(P * n, dtype=td, device=dev)
+        fx = torch.zeros(P * n * n, dtype=td, device=dev)
+        fu = torch.zeros(P * n * m, dtype=td, device=dev)
+        ta = tb = None
+        if tables is not None:
+            ta = torch.from_numpy(np.ascontiguousarray(tables[0], dtype=npd)).to(dev)
+            tb = torch.from_numpy(np.ascontiguousarray(tables[1], dtype=npd)).to(dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.ilqr_model_probe(int(model_id), _lib.F64 if npd == np.float64 else _lib.F32, float(dt), int(t),
+                                        ta.data_ptr() if ta is not None else None,
+                                        tb.data_ptr() if tb is not None else None,
+                                        xd.data_ptr(), ud.data_ptr(), xn.data_ptr(), fx.data_ptr(), fu.data_ptr(),
+                                        P, stream), "ilqr_model_probe")
+        out = (xn.cpu().numpy().astype(np.float64).reshape(P, n),
+               fx.cpu().numpy().astype(np.float64).reshape(P, n, n),
+               fu.cpu().numpy().astype(np.float64).reshape(P, n, m))
+    return out

@@ -58,6 +58,8 @@ typedef enum ilqr_model {
     ILQR_MODEL_DUBINS = 2,
     ILQR_MODEL_LTV = 3
 } ilqr_model;
+/* ids from here on are handed out by ilqr_load_model for dynamics compiled at run time */
+#define ILQR_MODEL_USER_BASE 16
 
 typedef enum ilqr_dtype { ILQR_F64 = 0, ILQR_F32 = 1 } ilqr_dtype;
 
@@ -121,7 +123,8 @@ typedef struct ilqr_buffers {
     int32_t *status;         /* in/out: ILQR_STATUS_* bits, or NULL */
     void *work;              /* scratch of ilqr_workspace_bytes() */
     const void *centers, *radius; /* barrier mode only */
-    const void *ltv_A, *ltv_B;    /* ILQR_MODEL_LTV only: [N-1][n][n], [N-1][n][m], shared by the batch */
+    const void *ltv_A, *ltv_B;    /* ILQR_MODEL_LTV: [N-1][n][n], [N-1][n][m], shared by the batch; a model loaded at
+                                     run time may read them as parameter tables of its own layout */
     void *hist_cost;         /* optional [hist_capacity][B]: min_cost after each iteration */
     int32_t *hist_alpha;     /* optional [hist_capacity][B]: accepted step index after each iteration */
     int32_t hist_capacity;
@@ -190,6 +193,25 @@ int ilqr_active_count(ilqr_handle *h, void *stream, int32_t *out);
  * reference layout [B][n], same element type) is not NULL; converged and iters are reset to 0.
  * Follow it with ilqr_solve (or ilqr_initial_cost and the phase calls). */
 int ilqr_shift(ilqr_handle *h, int32_t shift, const void *x0, void *stream);
+
+/* Dynamics compiled at run time.  The reference accepts any object with the System duck type
+ * (systems.py:4-24: model_f, compute_df_dx, compute_df_du) because it calls back into Python at
+ * every time step (ilqr.py:62, :87-88); here the same three functions are a device-code snippet
+ * compiled with hipcc against this library's kernel headers into a shared library of its own
+ * (ilqr_amd/jit.py writes and builds it).  ilqr_load_model opens such a library, checks that it
+ * was built from the same headers and returns the model id to put into ilqr_desc.model (the same
+ * path returns the same id).  ILQR_ERR_UNSUPPORTED: built against other headers. */
+int ilqr_load_model(const char *path, int32_t *model_id);
+/* state and control size of a model id (built in or loaded) */
+int ilqr_model_dims(int32_t model, int32_t *n, int32_t *m);
+/* The device dynamics of a model at `count` points, reference layout, element type `dtype`:
+ * x [count][n], u [count][m] -> x_next [count][n] (model_f, systems.py:33-40), fx [count][n][n]
+ * (compute_df_dx, systems.py:42-50), fu [count][n][m] (compute_df_du, systems.py:52-57) at time
+ * step t; entries a model declares structurally zero are returned as 0.  params_a / params_b are
+ * the tables the solver would get as ltv_A / ltv_B (NULL if the model reads none).  All device
+ * pointers.  For checking a device model against its host statement; not on the solve path. */
+int ilqr_model_probe(int32_t model, int32_t dtype, double dt, int32_t t, const void *params_a, const void *params_b, const void *x,
+                     const void *u, void *x_next, void *fx, void *fu, int32_t count, void *stream);
 
 /* layout helpers: reference layout [B][rows] (what numpy holds, e.g. states (B, N, n)
  * flattened) <-> tiled device layout [ceil(B/64)][rows][64]; elem_bytes 4 or 8; both

@@ -12,6 +12,7 @@
  *   systems.py:33-57   Car             -> model 0
  *   systems.py:64-90   CarAcceleration -> model 1
  *   systems.py:97-121  DubinsCar       -> model 2
+ *   any other System duck type (systems.py:4-24) -> model 100, dynamics called back
  *   cilqr.py:87-139  backward_pass with the per-step box QP -> orc_backward(),
  *                    solver_control_limited != 0
  *   constraints.py:20-26  BubbleConstraint.get_h / dh_dx -> barrier terms
@@ -36,7 +37,13 @@
 #define ORC_MAXN 12
 #define ORC_MAXM 4
 
-enum { ORC_CAR = 0, ORC_CARACC = 1, ORC_DUBINS = 2, ORC_LTV = 3 };
+enum { ORC_CAR = 0, ORC_CARACC = 1, ORC_DUBINS = 2, ORC_LTV = 3, ORC_CALLBACK = 100 };
+
+/* model 100: the dynamics are the caller's functions, the way the reference calls
+ * system.model_f (ilqr.py:62) and system.compute_df_dx / compute_df_du (ilqr.py:87-88) on
+ * whatever System object it was given */
+typedef void (*orc_user_f)(int32_t t, const double *x, const double *u, double *xn);
+typedef void (*orc_user_jac)(int32_t t, const double *x, const double *u, double *fx, double *fu);
 
 typedef struct ilqr_oracle_desc {
     int32_t n, m, N, model;
@@ -54,6 +61,8 @@ typedef struct ilqr_oracle_desc {
     double vel_bounds[2];
     const double *ltv_A;            /* model 3: [N-1][n][n], shared by the batch */
     const double *ltv_B;            /* model 3: [N-1][n][m] */
+    orc_user_f user_f;              /* model 100 */
+    orc_user_jac user_jac;          /* model 100 */
 } ilqr_oracle_desc;
 
 /* ---- dynamics ---------------------------------------------------------- */
@@ -86,6 +95,7 @@ static void model_f(const ilqr_oracle_desc *d, int t, const double *x, const dou
         xn[2] = x[2] + (v * u[1]) * dt;
         break;
     }
+    case ORC_CALLBACK: d->user_f(t, x, u, xn); break;
     default: { /* table-driven LTV: x+ = A_t x + B_t u (no reference counterpart) */
         const int n = d->n, m = d->m;
         const double *A = d->ltv_A + (size_t)t * n * n, *Bm = d->ltv_B + (size_t)t * n * m;
@@ -142,6 +152,7 @@ static void model_jac(const ilqr_oracle_desc *d, int t, const double *x, const d
         fu[2 * 2 + 1] = v * dt;
         break;
     }
+    case ORC_CALLBACK: d->user_jac(t, x, u, fx, fu); break;
     default:
         memcpy(fx, d->ltv_A + (size_t)t * n * n, sizeof(double) * n * n);
         memcpy(fu, d->ltv_B + (size_t)t * n * m, sizeof(double) * n * m);

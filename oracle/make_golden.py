@@ -113,6 +113,34 @@ def save(name, system, targets, init_inputs, x0, rec, init_states=None):
           f"tries={list(rec['hist_tries'])}  -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def make_bicycle():
+    from ilqr_amd.user_models import KinematicBicycle
+    s = KinematicBicycle()
+    s.set_cost(problems.BICYCLE_Q.copy(), problems.BICYCLE_R.copy())
+    s.set_control_limit(*problems.BICYCLE_LIMITS)
+    return s
+
+
+def make_pendulum():
+    from ilqr_amd.user_models import Pendulum
+    s = Pendulum()
+    s.set_cost(problems.PENDULUM_Q.copy(), problems.PENDULUM_R.copy())
+    s.set_control_limit(*problems.PENDULUM_LIMITS)
+    return s
+
+
+def user_models():
+    """Models outside the reference's systems.py: the reference SOLVER (ilqr.py) runs on their
+    numpy methods through its System duck type; the fixtures pin the run-time compiled device
+    dynamics of the same classes."""
+    for name, system, gen, picks in (("bicycle_N150", make_bicycle(), problems.bicycle_batch, (0, 2, 5)),
+                                     ("pendulum_N120", make_pendulum(), problems.pendulum_batch, (0, 1))):
+        p = gen(max(picks) + 1)
+        for b in picks:
+            rec = run_reference(system, p["target_states"][b], p["init_inputs"][b], p["x0"][b])
+            save(f"{name}_seed{b}", system, p["target_states"][b], p["init_inputs"][b], p["x0"][b], rec)
+
+
 def main():
     # Car, the demo construction (ilqr_demo.py:9-49), N=200 x 3 seeds and the demo's N=120
     for N, seed in ((200, 0), (200, 1), (200, 2), (120, 0)):
@@ -145,6 +173,7 @@ def main():
     tg, ui, _ = problems.demo_car(200, 3)
     car = make_car(limited=False)
     save("car_N200_nolimit", car, tg, ui, None, run_reference(car, tg, ui))
+    user_models()
     # 32 distinct problems of the batched generator: final results + cost history only
     B = 32
     p = problems.car_batch(B, 200)

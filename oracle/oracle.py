@@ -28,7 +28,32 @@ class Desc(C.Structure):
         ("lo", C.c_double * MAXM), ("hi", C.c_double * MAXM),
         ("vel_bounds", C.c_double * 2),
         ("ltv_A", C.c_void_p), ("ltv_B", C.c_void_p),
+        ("user_f", C.c_void_p), ("user_jac", C.c_void_p),
     ]
+
+
+MODEL_CALLBACK = 100
+_USER_F = C.CFUNCTYPE(None, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+_USER_JAC = C.CFUNCTYPE(None, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                        C.POINTER(C.c_double))
+
+
+def _callbacks(system):
+    """The System's own numpy methods as C callbacks: any object with the duck type of
+    ``systems.py:4-24`` can then be solved by the oracle, as by the reference (single thread
+    only: the callbacks run Python)."""
+    n, m = int(system.state_size), int(system.control_size)
+
+    def f(t, x, u, xn):
+        xa, ua = np.ctypeslib.as_array(x, (n,)), np.ctypeslib.as_array(u, (m,))
+        np.ctypeslib.as_array(xn, (n,))[:] = system.model_f(xa.copy(), ua.copy())
+
+    def jac(t, x, u, fx, fu):
+        xa, ua = np.ctypeslib.as_array(x, (n,)).copy(), np.ctypeslib.as_array(u, (m,)).copy()
+        np.ctypeslib.as_array(fx, (n * n,))[:] = np.asarray(system.compute_df_dx(xa, ua), dtype=float).ravel()
+        np.ctypeslib.as_array(fu, (n * m,))[:] = np.asarray(system.compute_df_du(xa, ua), dtype=float).ravel()
+
+    return _USER_F(f), _USER_JAC(jac)
 
 
 def build(force=False):
@@ -65,7 +90,11 @@ def make_desc(system, N, max_iter=30, alpha_floor=1e-4, lm=0.0, solver_control_l
     d = Desc()
     n, m = int(system.state_size), int(system.control_size)
     d.n, d.m, d.N = n, m, int(N)
-    d.model = MODEL_IDS[type(system).__name__]
+    d.model = MODEL_IDS.get(type(system).__name__, MODEL_CALLBACK)
+    if d.model == MODEL_CALLBACK:
+        cf, cj = _callbacks(system)
+        d._keep_cb = (cf, cj)  # the descriptor keeps the callback objects alive
+        d.user_f, d.user_jac = C.cast(cf, C.c_void_p), C.cast(cj, C.c_void_p)
     d.sys_control_limited = int(bool(system.control_limited))
     d.solver_control_limited = int(bool(solver_control_limited))
     d.barrier = int(bool(barrier))

@@ -32,8 +32,9 @@ def load_golden(name):
 
 def system_from_golden(g):
     """Rebuild the model-setup calls the fixture was generated with, on ilqr_amd.systems."""
-    from ilqr_amd import systems
-    s = getattr(systems, str(g["model"]))()
+    from ilqr_amd import systems, user_models
+    name = str(g["model"])
+    s = (getattr(systems, name, None) or getattr(user_models, name))()
     s.set_dt(float(g["dt"]))
     s.set_cost(np.array(g["Q"]), np.array(g["R"]))
     s.set_final_cost(np.array(g["Q_f"]))
