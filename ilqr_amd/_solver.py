@@ -49,19 +49,23 @@ class DeviceProblem:
         self.lib = _lib.lib()
         self.device = torch.device(device if device is not None else "cuda")
         self.np_dtype = _np_dtype(dtype)
-        if hasattr(system, "device_model"):
-            # dynamics compiled at run time (systems.DeviceSystem): built for this element type and
-            # for diagonal or dense cost weights, whichever the system has
+        model_id = getattr(system, "device_model_id", None)
+        if model_id is None:
+            # dynamics compiled at run time, for this element type and for diagonal or dense cost
+            # weights, whichever the system has: from the snippets of a systems.DeviceSystem, or for
+            # any other System duck type (systems.py:4-24) from a record of its numpy methods
             diag = all(np.count_nonzero(W - np.diag(np.diagonal(W))) == 0
                        for W in (np.asarray(system.Q, dtype=float), np.asarray(system.R, dtype=float),
                                  np.asarray(system.Q_f, dtype=float)))
-            model_id = system.device_model(self.np_dtype, diag)
-        else:
-            model_id = getattr(system, "device_model_id", None)
-        if model_id is None:
-            raise _lib.IlqrError(
-                f"{type(system).__name__} has no device dynamics; use Car, CarAcceleration, DubinsCar, LTVSystem "
-                "or derive the model from systems.DeviceSystem")
+            if hasattr(system, "device_model"):
+                model_id = system.device_model(self.np_dtype, diag)
+            else:
+                from . import trace
+                try:
+                    model_id = trace.traced_model(system, self.np_dtype, diag)
+                except trace.TraceError as e:
+                    raise _lib.IlqrError(f"{type(system).__name__} has no device dynamics and its numpy methods "
+                                         f"could not be recorded: {e}") from e
         self.t_dtype = torch.float64 if self.np_dtype == np.float64 else torch.float32
         self.B, self.N = int(B), int(N)
         self.n, self.m = int(system.state_size), int(system.control_size)

@@ -6,7 +6,7 @@ snippets of ``systems.DeviceSystem``.
 """
 import numpy as np
 
-from .systems import DeviceSystem
+from .systems import DeviceSystem, System
 
 
 class KinematicBicycle(DeviceSystem):
@@ -125,3 +125,33 @@ class Pendulum(DeviceSystem):
         J = np.zeros(x.shape[:-1] + (2, 1))
         J[..., 1, 0] = self.dt
         return J
+
+
+class NumpyBicycle(System):
+    """The same bicycle with numpy methods ONLY, in the idiom of the reference's own models
+    (``systems.py:33-57``: scalars picked out of ``x`` and ``u``, results assembled with
+    ``np.array``).  It has no device code at all: the solver records these methods once
+    (``ilqr_amd/trace.py``) and compiles the record."""
+
+    def __init__(self):
+        super().__init__(5, 2)
+        self.dt = 0.1
+        self.wheelbase = 2.5
+
+    def model_f(self, x, u):
+        theta, v, delta = x[2], x[3], x[4]
+        rate = np.array([[v * np.cos(theta)], [v * np.sin(theta)], [v * np.tan(delta) / self.wheelbase],
+                         [u[0]], [u[1]]])
+        return np.reshape(np.reshape(x, (-1, 1)) + rate * self.dt, (-1,))
+
+    def compute_df_dx(self, x, u):
+        theta, v, delta = x[2], x[3], x[4]
+        L, dt = self.wheelbase, self.dt
+        return np.array([[1.0, 0.0, -np.sin(theta) * v * dt, np.cos(theta) * dt, 0.0],
+                         [0.0, 1.0, np.cos(theta) * v * dt, np.sin(theta) * dt, 0.0],
+                         [0.0, 0.0, 1.0, np.tan(delta) / L * dt, v / (L * np.cos(delta) ** 2) * dt],
+                         [0.0, 0.0, 0.0, 1.0, 0.0],
+                         [0.0, 0.0, 0.0, 0.0, 1.0]])
+
+    def compute_df_du(self, x, u):
+        return np.array([[0.0, 0.0], [0.0, 0.0], [0.0, 0.0], [1.0, 0.0], [0.0, 1.0]]) * self.dt

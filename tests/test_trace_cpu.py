@@ -1,0 +1,109 @@
+"""CPU tests of ilqr_amd/trace.py: recording a System's numpy methods into device snippets."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from ilqr_amd import _lib, trace
+from ilqr_amd.systems import System
+from ilqr_amd.user_models import KinematicBicycle, NumpyBicycle
+
+
+def test_record_reproduces_the_methods_and_finds_the_sparsity():
+    s = NumpyBicycle()
+    t = trace.trace_system(s)
+    hand = KinematicBicycle()
+    assert np.array_equal(t["fx_pattern"], np.asarray(hand.fx_pattern))
+    assert np.array_equal(t["fu_pattern"], np.asarray(hand.fu_pattern))
+    # one sincos per distinct angle, no fused multiply-add, constants as literals of the element type
+    assert t["step"].count("sincos_<FAST>") == 2 and "fma_" not in t["step"]
+    assert "T(0.1)" in t["step"] and "xn[4] =" in t["step"]
+    assert "fx[2][4] =" in t["jac"] and "fx[0][0]" not in t["jac"] and "fu[0][0]" not in t["jac"]
+    # the record is checked against the methods inside trace_system; the same model stated the
+    # vectorised way agrees with it
+    rng = np.random.default_rng(0)
+    x, u = rng.normal(size=5), rng.normal(size=2)
+    assert np.allclose(s.model_f(x, u), hand.model_f(x, u), rtol=1e-15, atol=1e-15)
+    assert np.allclose(s.compute_df_dx(x, u), hand.compute_df_dx(x, u), rtol=1e-15, atol=1e-15)
+
+
+class _Exotic(System):
+    """every supported function once"""
+
+    def __init__(self):
+        super().__init__(3, 2)
+        self.dt = 0.01
+
+    def model_f(self, x, u):
+        a = np.exp(-x[0] ** 2) + np.sqrt(x[1] * x[1] + 1.0) - np.tanh(u[0])
+        b = np.arctan2(x[1], 2.0 + np.cos(x[2])) * np.log(3.0 + np.sin(x[0])) / (1.5 + abs(u[1]))
+        c = x[2] ** 3 - np.arctan(u[0]) + np.sinh(0.1 * x[0]) * np.cosh(0.1 * x[1]) + 2.0 ** (0.5 * x[2])
+        return np.array([x[0] + a * self.dt, x[1] + b * self.dt, x[2] + c * self.dt])
+
+    def compute_df_dx(self, x, u):
+        return np.array([[1.0, 0.0, 0.0], [x[1] * self.dt, 1.0, 0.0], [0.0, 0.0, 1.0 + 0.0 * x[0]]])
+
+    def compute_df_du(self, x, u):
+        return np.zeros((3, 2)) + np.array([[u[0], 0.0], [0.0, 0.0], [0.0, 1.0]]) * self.dt
+
+
+def test_function_table_and_constant_folding():
+    t = trace.trace_system(_Exotic())
+    for fn in ("exp(", "sqrt(", "tanh(", "atan2(", "log(", "fabs_(", "atan(", "sinh(", "cosh(", "pow("):
+        assert fn in t["step"], fn
+    assert t["fx_pattern"].tolist() == [[2, 0, 0], [1, 2, 0], [0, 0, 1]]   # 1 + 0*x stays an expression
+    assert t["fu_pattern"].tolist() == [[1, 0], [0, 0], [0, 1]]
+    assert "fu[2][1] = T(0.01);" in t["jac"]
+
+
+class _Branchy(System):
+    def __init__(self):
+        super().__init__(2, 1)
+        self.dt = 0.1
+
+    def model_f(self, x, u):
+        return np.array([x[0] + (x[1] if x[1] > 0 else 0.0) * self.dt, x[1] + u[0] * self.dt])
+
+    def compute_df_dx(self, x, u):
+        return np.eye(2)
+
+    def compute_df_du(self, x, u):
+        return np.array([[0.0], [self.dt]])
+
+
+class _Coercing(_Branchy):
+    def model_f(self, x, u):
+        x = np.asarray(x, dtype=float)
+        return x + np.array([x[1], u[0]]) * self.dt
+
+
+class _Stateful(_Branchy):
+    calls = 0
+
+    def model_f(self, x, u):
+        type(self).calls += 1
+        return np.array([x[0] + x[1] * self.dt * type(self).calls, x[1] + u[0] * self.dt])
+
+
+class _WrongShape(_Branchy):
+    def model_f(self, x, u):
+        return np.array([x[0] + x[1] * self.dt, x[1] + u[0] * self.dt])
+
+    def compute_df_du(self, x, u):
+        return np.array([[0.0, 0.0], [self.dt, 0.0]])
+
+
+@pytest.mark.parametrize("cls,needle", [(_Branchy, "compares or converts"), (_Coercing, "cannot be traced"),
+                                        (_Stateful, "does not compute the same values"),
+                                        (_WrongShape, "returned 4 values, expected 2")])
+def test_untraceable_models_are_refused_with_a_reason(cls, needle):
+    with pytest.raises(trace.TraceError, match=needle):
+        trace.trace_system(cls())
+
+
+def test_traced_model_compiles_and_registers():
+    mid = trace.traced_model(NumpyBicycle(), np.float64, True)
+    assert mid >= _lib.MODEL_USER_BASE
+    n, m = C.c_int32(), C.c_int32()
+    assert _lib.lib().ilqr_model_dims(mid, C.byref(n), C.byref(m)) == 0 and (n.value, m.value) == (5, 2)
+    assert trace.traced_model(NumpyBicycle(), np.float64, True) == mid
