@@ -357,8 +357,9 @@ int ilqr_bind(ilqr_handle *h, const ilqr_buffers *b) {
     if (!b->X || !b->U || !b->Xref || !b->K || !b->k || !b->J || !b->converged || !b->iters || !b->alpha_idx || !b->work)
         return ILQR_ERR_NOT_BOUND;
     if ((h->ctx.d.constraint_mode & ILQR_CONSTR_BARRIER) && (!b->centers || !b->radius)) return ILQR_ERR_NOT_BOUND;
-    // models loaded at run time may or may not read the tables: binding them is their caller's duty
     if (h->ctx.d.model == ILQR_MODEL_LTV && (!b->ltv_A || !b->ltv_B)) return ILQR_ERR_NOT_BOUND;
+    if (const LoadedModel *lm = loaded_model(h->ctx.d.model); lm && lm->info.needs_tables && (!b->ltv_A || !b->ltv_B))
+        return ILQR_ERR_NOT_BOUND; // its kernels would read through a null pointer
     if ((b->hist_cost || b->hist_alpha) && b->hist_capacity <= 0) return ILQR_ERR_INVALID;
     h->ctx.b = *b;
     h->ctx.bound = true;
@@ -652,6 +653,7 @@ int ilqr_model_probe(int32_t model, int32_t dtype, double dt, int32_t t, const v
     if (!ops && !model_lookup(model, dtype, false, n, m, hb, ops)) return ILQR_ERR_UNSUPPORTED;
     if (!ops) return ILQR_ERR_UNSUPPORTED;
     if (model == ILQR_MODEL_LTV && (!params_a || !params_b)) return ILQR_ERR_NOT_BOUND;
+    if (const LoadedModel *lm = loaded_model(model); lm && lm->info.needs_tables && (!params_a || !params_b)) return ILQR_ERR_NOT_BOUND;
     return hip_rc(ops->probe(dt, params_a, params_b, x, u, x_next, fx, fu, count, t, (hipStream_t)stream));
 }
 

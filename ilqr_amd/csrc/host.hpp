@@ -106,9 +106,10 @@ struct PluginInfo {
     int32_t abi;
     int32_t n, m;
     int32_t has_barrier; // the state starts with (px, py, v): the barrier terms of constraints.py:20-26 apply
+    int32_t needs_tables; // the dynamics read the shared tables (ilqr_buffers.ltv_A / ltv_B): they must be bound
     const ModelOps *(*ops)(int dtype, bool diag);
 };
-constexpr int32_t PLUGIN_ABI_VERSION = 1;
+constexpr int32_t PLUGIN_ABI_VERSION = 2;
 static inline int32_t plugin_abi() {
     return (int32_t)(PLUGIN_ABI_VERSION * 1000003u + sizeof(HostCtx) * 31u + sizeof(ilqr_desc) * 7u + sizeof(ilqr_buffers));
 }

@@ -179,6 +179,8 @@ def solve(d, target, states, inputs, centers=None, radius=None, converge=False, 
 def solve_batch(d, target, states, inputs, centers=None, radius=None, nthreads=1, history=True):
     """B problems (leading batch axis), in place on states/inputs."""
     B, mi = target.shape[0], d.max_iter
+    if d.model == MODEL_CALLBACK:
+        nthreads = 1  # the callbacks run Python: one thread
     mc = np.zeros(B)
     cv = np.zeros(B, dtype=np.int32)
     it = np.zeros(B, dtype=np.int32)

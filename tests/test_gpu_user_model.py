@@ -192,3 +192,18 @@ def test_numpy_only_model_is_recorded_and_solved(oracle):
         assert np.abs(xn[i] - s.model_f(x[i], u[i])).max() <= 1e-14 * 10
         assert np.abs(fx[i] - s.compute_df_dx(x[i], u[i])).max() <= 1e-14 * 10
         assert np.array_equal(fu[i], s.compute_df_du(x[i], u[i]))
+
+
+def test_time_varying_model_with_shared_tables():
+    """Snippets may read two tables shared by the batch (par_a / par_b) at the time index t."""
+    from ilqr_amd import jit, systems
+    from test_user_model_cpu import TABLE_FU, TABLE_FX, TABLE_JAC, TABLE_STEP
+    mid = jit.load_model(jit.build_model(jit.model_source(2, 1, TABLE_STEP, TABLE_JAC, TABLE_FX, TABLE_FU)))
+    rng = np.random.default_rng(9)
+    a, b = rng.normal(size=20), rng.normal(size=20)
+    x, u = rng.normal(size=(130, 2)), rng.normal(size=(130, 1))
+    for t in (0, 7, 19):
+        xn, fx, fu = systems.probe_model(mid, 0.1, x, u, t=t, tables=(a, b))
+        assert np.array_equal(xn[:, 0], x[:, 0] + a[t] * x[:, 1] * 0.1)
+        assert np.array_equal(xn[:, 1], x[:, 1] + b[t] * u[:, 0] * 0.1)
+        assert np.array_equal(fx[5], [[1.0, a[t] * 0.1], [0.0, 1.0]]) and np.array_equal(fu[5], [[0.0], [b[t] * 0.1]])

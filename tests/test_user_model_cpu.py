@@ -116,3 +116,30 @@ def test_host_statement_is_consistent(cls):
             P = np.asarray(s.fx_pattern)
             assert np.all(fx[P == 0] == 0) and np.all(fx[P == 2] == 1)
             assert np.all(fu[np.asarray(s.fu_pattern) == 0] == 0)
+
+
+TABLE_STEP = "xn[0] = x[0] + par_a[t] * x[1] * dt; xn[1] = x[1] + par_b[t] * u[0] * dt;"
+TABLE_JAC = "fx[0][1] = par_a[t] * dt; fu[1][0] = par_b[t] * dt;"
+TABLE_FX = [[2, 1], [0, 2]]
+TABLE_FU = [[0], [1]]
+
+
+def test_model_that_reads_tables_cannot_be_bound_without_them():
+    """A snippet that names par_a / par_b reads the shared tables: binding such a handle without
+    them must fail on the host instead of letting a kernel read through a null pointer."""
+    lib = _lib.lib()
+    src = jit.model_source(2, 1, TABLE_STEP, TABLE_JAC, TABLE_FX, TABLE_FU)
+    assert "needs_tables = 1" in src
+    assert "needs_tables = 0" in jit.model_source(2, 1, Pendulum.device_step, Pendulum.device_jac)
+    mid = jit.load_model(jit.build_model(src))
+    h = C.c_void_p()
+    assert lib.ilqr_create(C.byref(_desc(mid, 2, 1)), C.byref(h)) == 0
+    b = _lib.Buffers()
+    for name in ("X", "U", "Xref", "K", "k", "J", "converged", "iters", "alpha_idx", "work"):
+        setattr(b, name, 4096)   # never dereferenced: ilqr_bind only records the pointers
+    assert lib.ilqr_bind(h, C.byref(b)) == -3
+    b.ltv_A = b.ltv_B = 4096
+    assert lib.ilqr_bind(h, C.byref(b)) == 0
+    lib.ilqr_destroy(h)
+    # the probe refuses as well, before anything is launched
+    assert lib.ilqr_model_probe(mid, _lib.F64, 0.1, 0, None, None, 4096, 4096, 4096, 4096, 4096, 1, None) == -3

@@ -1,0 +1,9 @@
+import sys, time
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+import numpy as np, torch
+import bench_configs as bc
+for name in ("cilqr16384", "car16384"):
+    opt, desc = bc.build(name)
+    opt()
+    it = np.asarray(opt.iterations)
+    print(name, "mean", it.mean(), "max", it.max(), "pcts", np.percentile(it, [50, 90, 99, 99.9]).tolist(), "hist/10", np.bincount(it // 10).tolist(), flush=True)

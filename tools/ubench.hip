@@ -10,7 +10,14 @@
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 // separate arrays: A0 (4 rows/step), A1 (4 rows/step), A2 (2 rows/step) read; W0 (8 rows/step), W1 (2 rows/step) written
-template <int PF, bool REVERSE, bool DO_WRITE, int FLOPS>
+template <int NT> __device__ __forceinline__ void st(double *p, double v) {
+    if (NT & 1) __builtin_nontemporal_store(v, p); else *p = v;
+}
+template <int NT> __device__ __forceinline__ double ld(const double *p) {
+    return (NT & 2) ? __builtin_nontemporal_load(p) : *p;
+}
+// NT bit 0: nontemporal stores, bit 1: nontemporal loads; DO_READ false: write-only
+template <int PF, bool REVERSE, bool DO_WRITE, int FLOPS, int NT = 0, bool DO_READ = true>
 __global__ __launch_bounds__(64) void pattern_separate(const double *A0, const double *A1, const double *A2, double *W0, double *W1, int T) {
     const int tile = blockIdx.x, ln = threadIdx.x;
     const double *a0 = A0 + (size_t)tile * T * 4 * 64 + ln;
@@ -21,9 +28,9 @@ __global__ __launch_bounds__(64) void pattern_separate(const double *A0, const d
     double ring[PF][10];
     auto load = [&](int t, double (&r)[10]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { r[i] = a0[(t * 4 + i) * 64]; r[4 + i] = a1[(t * 4 + i) * 64]; }
+        for (int i = 0; i < 4; ++i) { r[i] = DO_READ ? ld<NT>(a0 + (t * 4 + i) * 64) : 1.0; r[4 + i] = DO_READ ? ld<NT>(a1 + (t * 4 + i) * 64) : 2.0; }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) r[8 + i] = a2[(t * 2 + i) * 64];
+        for (int i = 0; i < 2; ++i) r[8 + i] = DO_READ ? ld<NT>(a2 + (t * 2 + i) * 64) : 3.0;
     };
 #pragma unroll
     for (int s = 0; s < PF; ++s) { int t = REVERSE ? T - 1 - s : s; if (s < T) load(t, ring[s]); }
@@ -47,9 +54,9 @@ __global__ __launch_bounds__(64) void pattern_separate(const double *A0, const d
             acc = v;
             if (DO_WRITE) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) w0[(t * 8 + i) * 64] = v + i;
+                for (int i = 0; i < 8; ++i) st<NT>(w0 + (t * 8 + i) * 64, v + i);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) w1[(t * 2 + i) * 64] = v - i;
+                for (int i = 0; i < 2; ++i) st<NT>(w1 + (t * 2 + i) * 64, v - i);
             }
         }
     }
@@ -144,6 +151,13 @@ int main() {
         time_ms([&] { hipLaunchKernelGGL((pattern_separate<PF, REV, WR, FL>), dim3(tiles), dim3(64), 0, 0, A0, A1, A2, W0, W1, T); }), WR)
 #define RUN_MRG(PF, REV, WR, FL) report("merged   PF=" #PF " rev=" #REV " write=" #WR " flops=" #FL, \
         time_ms([&] { hipLaunchKernelGGL((pattern_merged<PF, REV, WR, FL>), dim3(tiles), dim3(64), 0, 0, AM, WM, T); }), WR)
+#define RUN_NT(PF, NT, RD) { float ms_ = time_ms([&] { hipLaunchKernelGGL((pattern_separate<PF, true, true, 0, NT, RD>), dim3(tiles), dim3(64), 0, 0, A0, A1, A2, W0, W1, T); }); \
+        printf("separate PF=" #PF " nt=" #NT " read=" #RD " %8.3f ms  %7.1f GB/s\n", ms_, ((RD ? rd : 0) + wr) / ms_ / 1e6); }
+    RUN_NT(3, 1, true);
+    RUN_NT(3, 2, true);
+    RUN_NT(3, 3, true);
+    RUN_NT(3, 0, false);
+    RUN_NT(3, 1, false);
     RUN_SEP(1, true, true, 0);
     RUN_SEP(3, true, true, 0);
     RUN_SEP(8, true, true, 0);
