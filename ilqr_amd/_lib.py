@@ -11,7 +11,7 @@ MAX_N, MAX_M = 12, 4
 MODEL_USER_BASE = 16
 F64, F32 = 0, 1
 CONSTR_NONE, CONSTR_BOXQP, CONSTR_BARRIER = 0, 1, 2
-STATUS_NONPD, STATUS_SINGULAR, STATUS_NONFINITE = 1, 2, 4
+STATUS_NONPD, STATUS_SINGULAR, STATUS_NONFINITE, STATUS_QP_FAILED = 1, 2, 4, 8
 TILE = 64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -53,6 +53,12 @@ class Buffers(C.Structure):
     ]
 
 
+class SqpOpts(C.Structure):
+    _fields_ = [("max_iter", C.c_int32), ("init_input_fixed", C.c_int32), ("qp_max_iter", C.c_int32),
+                ("reserved", C.c_int32), ("eps", C.c_double), ("cost_eps", C.c_double), ("qp_tol", C.c_double),
+                ("qp_sigma", C.c_double)]
+
+
 _SIGNATURES = {
     "ilqr_create": (C.c_int, [C.POINTER(Desc), C.POINTER(C.c_void_p)]),
     "ilqr_destroy": (None, [C.c_void_p]),
@@ -77,6 +83,12 @@ _SIGNATURES = {
     "ilqr_model_dims": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ilqr_model_probe": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "ilqr_sqp_workspace_bytes": (C.c_size_t, [C.c_void_p]),
+    "ilqr_sqp_solved_inputs": (C.c_void_p, [C.c_void_p, C.c_void_p]),
+    "ilqr_sqp_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ilqr_sqp_qp": (C.c_int, [C.c_void_p, C.POINTER(SqpOpts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ilqr_sqp_search": (C.c_int, [C.c_void_p, C.POINTER(SqpOpts), C.c_void_p, C.c_int32, C.c_void_p]),
+    "ilqr_sqp_solve": (C.c_int, [C.c_void_p, C.POINTER(SqpOpts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ilqr_strerror": (C.c_char_p, [C.c_int]),
     "ilqr_last_hip_error": (C.c_int, []),
     "ilqr_desc_size": (C.c_int32, []),

@@ -2,6 +2,7 @@
 // Host-only logic: descriptor validation, dispatch to the kernel tables and
 // the iteration driver.  Nothing here allocates device memory.
 #include "host.hpp"
+#include "sqp.hpp"
 
 #include <cmath>
 #include <cstdlib>
@@ -655,6 +656,114 @@ int ilqr_model_probe(int32_t model, int32_t dtype, double dt, int32_t t, const v
     if (model == ILQR_MODEL_LTV && (!params_a || !params_b)) return ILQR_ERR_NOT_BOUND;
     if (const LoadedModel *lm = loaded_model(model); lm && lm->info.needs_tables && (!params_a || !params_b)) return ILQR_ERR_NOT_BOUND;
     return hip_rc(ops->probe(dt, params_a, params_b, x, u, x_next, fx, fu, count, t, (hipStream_t)stream));
+}
+
+// ---- sequential QP (sqp.hpp) -----------------------------------------------------------------
+namespace {
+struct SqpLayout {
+    size_t S, LAM, DU, UQ, XQ, total;
+};
+SqpLayout sqp_layout(const ilqr_desc &d) {
+    const size_t e = 8, Bp = ((size_t)d.B + TILE - 1) / TILE * TILE;
+    const size_t N = d.N, T1 = d.N - 1, n = d.n, m = d.m, NR = 3 + 2 * m;
+    SqpLayout l;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return at;
+    };
+    l.S = take(Bp * N * NR * e);
+    l.LAM = take(Bp * N * NR * e);
+    l.DU = take(Bp * T1 * m * e);
+    l.UQ = take(Bp * T1 * m * e);
+    l.XQ = take(Bp * N * n * e);
+    l.total = off;
+    return l;
+}
+const SqpOps *sqp_check(const ilqr_handle *h, int &rc) {
+    rc = ILQR_OK;
+    if (!h) {
+        rc = ILQR_ERR_INVALID;
+        return nullptr;
+    }
+    if (!h->ctx.bound) {
+        rc = ILQR_ERR_NOT_BOUND;
+        return nullptr;
+    }
+    const SqpOps *ops = sqp_ops(h->ctx.d.model, h->ctx.d.dtype);
+    // the constraint rows need centers and radius, which a handle only demands in barrier mode
+    if (!ops || !(h->ctx.d.constraint_mode & ILQR_CONSTR_BARRIER)) rc = ILQR_ERR_UNSUPPORTED;
+    if (h->whole.packed) rc = ILQR_ERR_INVALID;
+    return rc == ILQR_OK ? ops : nullptr;
+}
+int sqp_args(const ilqr_handle *h, const ilqr_sqp_opts *o, void *work, const void *u0, bool need_u0, int32_t *qp_iters, SqpArgs &a) {
+    if (!o || !work) return ILQR_ERR_INVALID;
+    if (o->max_iter < 0 || o->qp_max_iter < 0 || !(o->eps > 0.0) || !(o->cost_eps >= 0.0) || o->qp_tol < 0.0 || o->qp_sigma < 0.0 ||
+        o->qp_sigma >= 1.0)
+        return ILQR_ERR_INVALID;
+    if (need_u0 && o->init_input_fixed && !u0) return ILQR_ERR_NOT_BOUND;
+    const SqpLayout l = sqp_layout(h->ctx.d);
+    char *w = (char *)work;
+    a.S = w + l.S;
+    a.LAM = w + l.LAM;
+    a.DU = w + l.DU;
+    a.UQ = w + l.UQ;
+    a.XQ = w + l.XQ;
+    a.U0 = o->init_input_fixed ? u0 : nullptr;
+    a.qp_iters = qp_iters;
+    a.eps = o->eps;
+    a.cost_eps = o->cost_eps;
+    a.qp_tol = o->qp_tol > 0.0 ? o->qp_tol : 1e-10;
+    a.qp_sigma = o->qp_sigma > 0.0 ? o->qp_sigma : 0.2;
+    a.qp_max_iter = o->qp_max_iter > 0 ? o->qp_max_iter : 200;
+    a.n_alphas = alphas_from_floor(o->eps); // the step sizes the loop of sqp.py:156-171 can visit
+    a.fixed = o->init_input_fixed ? 1 : 0;
+    return a.n_alphas > 0 ? ILQR_OK : ILQR_ERR_INVALID;
+}
+} // namespace
+
+size_t ilqr_sqp_workspace_bytes(const ilqr_handle *h) { return h ? sqp_layout(h->ctx.d).total : 0; }
+
+void *ilqr_sqp_solved_inputs(const ilqr_handle *h, void *work) { return (h && work) ? (char *)work + sqp_layout(h->ctx.d).UQ : nullptr; }
+
+int ilqr_sqp_begin(ilqr_handle *h, void *stream) {
+    int rc;
+    const SqpOps *ops = sqp_check(h, rc);
+    if (!ops) return rc;
+    h->ctx.reroll = false;
+    return hip_rc(ops->init(h->ctx, (hipStream_t)stream));
+}
+
+int ilqr_sqp_qp(ilqr_handle *h, const ilqr_sqp_opts *opts, void *work, const void *u0, int32_t *qp_iters, void *stream) {
+    int rc;
+    const SqpOps *ops = sqp_check(h, rc);
+    if (!ops) return rc;
+    SqpArgs a;
+    rc = sqp_args(h, opts, work, u0, true, qp_iters, a);
+    if (rc != ILQR_OK) return rc;
+    return hip_rc(ops->qp(h->ctx, a, (hipStream_t)stream));
+}
+
+int ilqr_sqp_search(ilqr_handle *h, const ilqr_sqp_opts *opts, void *work, int32_t iteration, void *stream) {
+    int rc;
+    const SqpOps *ops = sqp_check(h, rc);
+    if (!ops) return rc;
+    if (iteration < 0) return ILQR_ERR_INVALID;
+    SqpArgs a;
+    rc = sqp_args(h, opts, work, nullptr, false, nullptr, a);
+    if (rc != ILQR_OK) return rc;
+    return hip_rc(ops->search(h->ctx, a, iteration, (hipStream_t)stream));
+}
+
+int ilqr_sqp_solve(ilqr_handle *h, const ilqr_sqp_opts *opts, void *work, const void *u0, int32_t *qp_iters, void *stream) {
+    int rc = ilqr_sqp_begin(h, stream);
+    for (int it = 0; rc == ILQR_OK && it < (opts ? opts->max_iter : 0); ++it) {
+        rc = ilqr_sqp_qp(h, opts, work, u0, qp_iters, stream);
+        if (rc == ILQR_OK) rc = ilqr_sqp_search(h, opts, work, it, stream);
+    }
+    if (rc == ILQR_OK && !opts) rc = ILQR_ERR_INVALID;
+    return rc;
 }
 
 const char *ilqr_strerror(int code) {

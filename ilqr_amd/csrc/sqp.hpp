@@ -1,0 +1,666 @@
+// Batched sequential-QP solver (sqp.py of the reference) for models whose state starts with
+// (px, py, v), the layout constraints.py:12 is written for.  One lane per problem, tiled
+// structure-of-arrays buffers as everywhere else in this library.
+//
+//   sqp_init_kernel    sqp.py:139-140   min_cost = inf, converge = False
+//   sqp_qp_kernel      sqp.py:145-148   the QP of compute_P_q / compute_A_l_u (sqp.py:77-134) is
+//                      never assembled: its blocks are recomputed from the linearisation point
+//                      in every sweep.  The reference hands the sparse QP to OSQP; here it is
+//                      solved by a primal-dual path-following iteration whose Newton step is an
+//                      LQR problem (all inequality rows act on one time step), solved exactly by
+//                      a Riccati recursion: three sweeps over the horizon per iteration.
+//   sqp_search_kernel  sqp.py:149-171   the step-halving search on the simulated cost, all step
+//                      sizes of a problem on neighbouring lanes, and the accepted step written
+//                      in place.
+#pragma once
+#include "kernels.hpp"
+
+namespace ilqr {
+
+constexpr int ILQR_STATUS_QP_FAILED_ = 8;
+
+struct SqpArgs {
+    void *S, *LAM;     // slacks and multipliers, rows = N * NR
+    void *DU;          // Newton direction of the inputs, rows = (N-1) * NU
+    void *UQ, *XQ;     // QP iterate: inputs (rows (N-1)*NU) and states (rows N*NX); UQ ends as the solved inputs
+    const void *U0;    // fixed first input (rows NU) or null (sqp.py:111-112)
+    int32_t *qp_iters; // per problem: iterations of the last QP solve (may be null)
+    double eps, cost_eps, qp_tol, qp_sigma;
+    int32_t qp_max_iter, n_alphas, fixed;
+};
+
+template <typename T, class M> struct SqpRows {
+    static constexpr int NX = M::NX, NU = M::NU, NR = 3 + 2 * NU;
+    // row j of time step i as  grad . (x or u) <= bound ; live = the row exists
+    T gx[2];           // bubble row: gradient wrt (px, py) at the linearisation point (constraints.py:24-25)
+    T bnd[NR];
+    bool live[NR];
+    template <class P>
+    __device__ __forceinline__ void setup(const P &p, int i, int T1, const T (&xb)[NX], T cx, T cy, T rad, bool fixed0) {
+        const T ex = xb[0] - cx, ey = xb[1] - cy;
+        gx[0] = T(2) * ex;
+        gx[1] = T(2) * ey;
+        const T h = ex * ex + ey * ey - rad * rad;                  // constraints.py:20-22
+        bnd[0] = gx[0] * xb[0] + gx[1] * xb[1] - h;                  // constraints.py:28-30
+        bnd[1] = -p.vlo;
+        bnd[2] = p.vhi;
+        const bool st = i >= 1; // the rows of step 0 only test the given initial state
+        live[0] = st;
+        live[1] = st && (-bnd[1] > -inf_<T>());
+        live[2] = st && (bnd[2] < inf_<T>());
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            bnd[3 + 2 * j] = -p.qlo[j];
+            bnd[4 + 2 * j] = p.qhi[j];
+            const bool in = i < T1 && !(fixed0 && i == 0);
+            live[3 + 2 * j] = in && (p.qlo[j] > -inf_<T>());
+            live[4 + 2 * j] = in && (p.qhi[j] < inf_<T>());
+        }
+    }
+    __device__ __forceinline__ T value(int j, const T (&x)[NX], const T (&u)[NU]) const {
+        if (j == 0) return gx[0] * x[0] + gx[1] * x[1];
+        if (j == 1) return -x[2];
+        if (j == 2) return x[2];
+        const int c = (j - 3) >> 1;
+        return ((j - 3) & 1) ? u[c] : -u[c];
+    }
+    // directional derivative of row j along (dx, du)
+    __device__ __forceinline__ T along(int j, const T (&dx)[NX], const T (&du)[NU]) const { return value(j, dx, du); }
+};
+
+// linearisation x+ = A x + B u + c of the model at (xb, ub) with c = xb_next - A xb - B ub (sqp.py:91-94, :124-126)
+template <typename T, class M, class P>
+__device__ __forceinline__ void sqp_linearise(const P &p, int i, const T (&xb)[M::NX], const T (&ub)[M::NU], const T (&xbn)[M::NX],
+                                              T (&A)[M::NX][M::NX], T (&B)[M::NX][M::NU], T (&c)[M::NX]) {
+    constexpr int NX = M::NX, NU = M::NU;
+#pragma unroll
+    for (int a = 0; a < NX; ++a) {
+#pragma unroll
+        for (int b = 0; b < NX; ++b) A[a][b] = M::fx_one(a, b) ? T(1) : T(0);
+#pragma unroll
+        for (int b = 0; b < NU; ++b) B[a][b] = T(0);
+    }
+    bool bad = false;
+    M::template jac<false>(p, i, xb, ub, A, B, bad);
+#pragma unroll
+    for (int a = 0; a < NX; ++a) {
+        T s = xbn[a];
+#pragma unroll
+        for (int b = 0; b < NX; ++b) s -= A[a][b] * xb[b];
+#pragma unroll
+        for (int b = 0; b < NU; ++b) s -= B[a][b] * ub[b];
+        c[a] = s;
+    }
+}
+
+template <typename T> __global__ __launch_bounds__(64) void sqp_init_kernel(T *J, int32_t *converged, int32_t *iters, int32_t *alpha_idx, int B) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    J[b] = inf_<T>();
+    converged[b] = 0;
+    iters[b] = 0;
+    alpha_idx[b] = -1;
+}
+
+template <typename T, class M>
+__global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, SqpArgs a) {
+    constexpr int NX = M::NX, NU = M::NU, NR = 3 + 2 * NU;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    const bool valid = b < p.B;
+    const bool active = valid && p.converged[valid ? b : 0] == 0;
+    if (__ballot(active) == 0ull) return;
+    const int N = p.N, T1 = N - 1, tile = blockIdx.x, ln = threadIdx.x;
+    const T *Xb = tile_ptr(p.X, tile, N * NX, ln);          // linearisation point (self.states)
+    const T *Ub = tile_ptr(p.U, tile, T1 * NU, ln);         // (self.inputs)
+    const T *Rt = tile_ptr(p.Xref, tile, N * NX, ln);
+    const T *Cp = tile_ptr(p.centers, tile, N * 2, ln);
+    const T *Dp = tile_ptr(p.radius, tile, N, ln);
+    T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
+    T *Sp = tile_ptr((T *)a.S, tile, N * NR, ln);
+    T *Lp = tile_ptr((T *)a.LAM, tile, N * NR, ln);
+    T *DUp = tile_ptr((T *)a.DU, tile, T1 * NU, ln);
+    T *UQp = tile_ptr((T *)a.UQ, tile, T1 * NU, ln);
+    T *XQp = tile_ptr((T *)a.XQ, tile, N * NX, ln);
+    const T *U0p = a.U0 ? tile_ptr((const T *)a.U0, tile, NU, ln) : nullptr;
+    const bool fixed0 = a.fixed != 0 && U0p != nullptr;
+    const T sigma = (T)a.qp_sigma, tol = (T)a.qp_tol;
+    using Rows = SqpRows<T, M>;
+
+    auto load_x = [&](const T *base, int i, T (&x)[NX]) {
+#pragma unroll
+        for (int q = 0; q < NX; ++q) x[q] = base[(size_t)(i * NX + q) * TILE];
+    };
+    auto load_u = [&](const T *base, int i, T (&u)[NU]) {
+#pragma unroll
+        for (int q = 0; q < NU; ++q) u[q] = base[(size_t)(i * NU + q) * TILE];
+    };
+
+    // ---- start: inputs = current inputs, states by the linearised dynamics, slacks from the rows
+    T mu = T(0);
+    int nlive = 0;
+    {
+        T x[NX], xb[NX], xbn[NX];
+        load_x(Xb, 0, xb);
+#pragma unroll
+        for (int q = 0; q < NX; ++q) x[q] = xb[q];       // x0 = states[0] (sqp.py:37, :120)
+        for (int i = 0; i < N; ++i) {
+            T ub[NU], u[NU];
+#pragma unroll
+            for (int q = 0; q < NU; ++q) ub[q] = u[q] = T(0);
+            if (i < T1) {
+                load_u(Ub, i, ub);
+#pragma unroll
+                for (int q = 0; q < NU; ++q) u[q] = (fixed0 && i == 0) ? U0p[(size_t)q * TILE] : ub[q];
+            }
+            Rows rows;
+            rows.setup(p, i, T1, xb, Cp[(size_t)(i * 2) * TILE], Cp[(size_t)(i * 2 + 1) * TILE], Dp[(size_t)i * TILE], fixed0);
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                T s = T(1);
+                if (rows.live[j]) {
+                    const T gap = rows.bnd[j] - rows.value(j, x, u);
+                    s = gap > T(1) ? gap : T(1);
+                    mu += s;
+                    ++nlive;
+                }
+                if (active) {
+                    Sp[(size_t)(i * NR + j) * TILE] = s;
+                    Lp[(size_t)(i * NR + j) * TILE] = T(1);
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int q = 0; q < NX; ++q) XQp[(size_t)(i * NX + q) * TILE] = x[q];
+            }
+            if (i < T1) {
+                if (active) {
+#pragma unroll
+                    for (int q = 0; q < NU; ++q) UQp[(size_t)(i * NU + q) * TILE] = u[q];
+                }
+                load_x(Xb, i + 1, xbn);
+                T A[NX][NX], Bm[NX][NU], c[NX], xn[NX];
+                sqp_linearise<T, M>(p, i, xb, ub, xbn, A, Bm, c);
+#pragma unroll
+                for (int r = 0; r < NX; ++r) {
+                    T s = c[r];
+#pragma unroll
+                    for (int q = 0; q < NX; ++q) s += A[r][q] * x[q];
+#pragma unroll
+                    for (int q = 0; q < NU; ++q) s += Bm[r][q] * u[q];
+                    xn[r] = s;
+                }
+#pragma unroll
+                for (int q = 0; q < NX; ++q) {
+                    x[q] = xn[q];
+                    xb[q] = xbn[q];
+                }
+            }
+        }
+        mu = nlive > 0 ? mu / (T)nlive : T(0);
+    }
+
+    bool done = !active, failed = false;
+    int it = 0;
+    for (; it < a.qp_max_iter; ++it) {
+        if (__ballot(!done) == 0ull) break;
+        // ---- backward sweep: Riccati recursion of the Newton step
+        {
+            T Pm[NX][NX], pv[NX], xbn[NX];
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                pv[r] = T(0);
+                xbn[r] = T(0);
+#pragma unroll
+                for (int q = 0; q < NX; ++q) Pm[r][q] = T(0);
+            }
+            bool bad = false;
+            for (int i = T1; i >= 0; --i) {
+                T xb[NX], ub[NU], xq[NX], uq[NU], xr[NX];
+                load_x(Xb, i, xb);
+                load_x(XQp, i, xq);
+                load_x(Rt, i, xr);
+#pragma unroll
+                for (int q = 0; q < NU; ++q) ub[q] = uq[q] = T(0);
+                if (i < T1) {
+                    load_u(Ub, i, ub);
+                    load_u(UQp, i, uq);
+                }
+                Rows rows;
+                rows.setup(p, i, T1, xb, Cp[(size_t)(i * 2) * TILE], Cp[(size_t)(i * 2 + 1) * TILE], Dp[(size_t)i * TILE], fixed0);
+                const T *W = i == T1 ? p.Qf : p.Q;
+                T Hx[NX][NX], gxv[NX], Hu[NU][NU], guv[NU];
+#pragma unroll
+                for (int r = 0; r < NX; ++r) {
+                    T s = T(0);
+#pragma unroll
+                    for (int q = 0; q < NX; ++q) {
+                        Hx[r][q] = W[r * NX + q];
+                        s += W[r * NX + q] * (xq[q] - xr[q]);
+                    }
+                    gxv[r] = s;
+                }
+#pragma unroll
+                for (int r = 0; r < NU; ++r) {
+                    T s = T(0);
+#pragma unroll
+                    for (int q = 0; q < NU; ++q) {
+                        Hu[r][q] = p.R[r * NU + q];
+                        s += p.R[r * NU + q] * uq[q];
+                    }
+                    guv[r] = s;
+                }
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    if (!rows.live[j]) continue;
+                    const T s = Sp[(size_t)(i * NR + j) * TILE], lam = Lp[(size_t)(i * NR + j) * TILE];
+                    const T rp = rows.value(j, xq, uq) + s - rows.bnd[j];
+                    const T rc = s * lam - sigma * mu;
+                    const T coef = lam + (lam * rp - rc) / s;
+                    const T d = lam / s;
+                    if (j == 0) {
+                        Hx[0][0] += d * rows.gx[0] * rows.gx[0];
+                        Hx[0][1] += d * rows.gx[0] * rows.gx[1];
+                        Hx[1][0] += d * rows.gx[1] * rows.gx[0];
+                        Hx[1][1] += d * rows.gx[1] * rows.gx[1];
+                        gxv[0] += coef * rows.gx[0];
+                        gxv[1] += coef * rows.gx[1];
+                    } else if (j < 3) {
+                        Hx[2][2] += d;
+                        gxv[2] += j == 1 ? -coef : coef;
+                    } else {
+                        const int cu = (j - 3) >> 1;
+                        Hu[cu][cu] += d;
+                        guv[cu] += ((j - 3) & 1) ? coef : -coef;
+                    }
+                }
+                if (i == T1) {
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) {
+                        pv[r] = gxv[r];
+#pragma unroll
+                        for (int q = 0; q < NX; ++q) Pm[r][q] = Hx[r][q];
+                    }
+                } else {
+                    T A[NX][NX], Bm[NX][NU], c[NX];
+                    sqp_linearise<T, M>(p, i, xb, ub, xbn, A, Bm, c);
+                    // PA = P A, PB = P B
+                    T PA[NX][NX], PB[NX][NU];
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) {
+#pragma unroll
+                        for (int q = 0; q < NX; ++q) {
+                            T s = T(0);
+#pragma unroll
+                            for (int w = 0; w < NX; ++w) s += Pm[r][w] * A[w][q];
+                            PA[r][q] = s;
+                        }
+#pragma unroll
+                        for (int q = 0; q < NU; ++q) {
+                            T s = T(0);
+#pragma unroll
+                            for (int w = 0; w < NX; ++w) s += Pm[r][w] * Bm[w][q];
+                            PB[r][q] = s;
+                        }
+                    }
+                    T Qxx[NX][NX], Qx[NX], Qux[NU][NX], Quu[NU][NU], Qu[NU];
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) {
+                        T s = gxv[r];
+#pragma unroll
+                        for (int w = 0; w < NX; ++w) s += A[w][r] * pv[w];
+                        Qx[r] = s;
+#pragma unroll
+                        for (int q = 0; q < NX; ++q) {
+                            T t = Hx[r][q];
+#pragma unroll
+                            for (int w = 0; w < NX; ++w) t += A[w][r] * PA[w][q];
+                            Qxx[r][q] = t;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < NU; ++r) {
+                        T s = guv[r];
+#pragma unroll
+                        for (int w = 0; w < NX; ++w) s += Bm[w][r] * pv[w];
+                        Qu[r] = s;
+#pragma unroll
+                        for (int q = 0; q < NX; ++q) {
+                            T t = T(0);
+#pragma unroll
+                            for (int w = 0; w < NX; ++w) t += Bm[w][r] * PA[w][q];
+                            Qux[r][q] = t;
+                        }
+#pragma unroll
+                        for (int q = 0; q < NU; ++q) {
+                            T t = Hu[r][q];
+#pragma unroll
+                            for (int w = 0; w < NX; ++w) t += Bm[w][r] * PB[w][q];
+                            Quu[r][q] = t;
+                        }
+                    }
+                    T rhs[NU][NX + 1]; // columns 0..NX-1: -Qux, column NX: -Qu
+#pragma unroll
+                    for (int r = 0; r < NU; ++r) {
+#pragma unroll
+                        for (int q = 0; q < NX; ++q) rhs[r][q] = -Qux[r][q];
+                        rhs[r][NX] = -Qu[r];
+                    }
+                    solve_quu<T, NU, NX + 1, true>(Quu, rhs, bad);
+                    if (fixed0 && i == 0) { // the first input does not move: du_0 = 0
+#pragma unroll
+                        for (int r = 0; r < NU; ++r)
+#pragma unroll
+                            for (int q = 0; q <= NX; ++q) rhs[r][q] = T(0);
+                    }
+                    if (!done) {
+#pragma unroll
+                        for (int r = 0; r < NU; ++r) {
+                            kp[(size_t)(i * NU + r) * TILE] = rhs[r][NX];
+#pragma unroll
+                            for (int q = 0; q < NX; ++q) Kp[(size_t)((i * NU + r) * NX + q) * TILE] = rhs[r][q];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) {
+                        T s = Qx[r];
+#pragma unroll
+                        for (int w = 0; w < NU; ++w) s += rhs[w][r] * Qu[w];
+                        pv[r] = s;
+#pragma unroll
+                        for (int q = 0; q < NX; ++q) {
+                            T t = Qxx[r][q];
+#pragma unroll
+                            for (int w = 0; w < NU; ++w) t += rhs[w][r] * Qux[w][q];
+                            Pm[r][q] = t;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NX; ++q) xbn[q] = xb[q];
+            }
+            failed = failed || bad;
+        }
+        // ---- forward sweeps: 0 = direction and step length, 1 = apply and measure
+        T amax = T(1), alpha = T(0), gap = T(0), rpmax = T(0), dumax = T(0);
+        for (int pass = 0; pass < 2; ++pass) {
+            T dx[NX], x[NX], xb[NX], xbn[NX];
+            load_x(Xb, 0, xb);
+#pragma unroll
+            for (int q = 0; q < NX; ++q) {
+                dx[q] = T(0);
+                x[q] = xb[q];
+            }
+            if (pass == 1) {
+                const T am = T(0.995) * amax;
+                alpha = am < T(1) ? am : T(1);
+            }
+            for (int i = 0; i < N; ++i) {
+                T ub[NU], uq[NU], xq[NX], du[NU];
+                load_x(XQp, i, xq);
+#pragma unroll
+                for (int q = 0; q < NU; ++q) ub[q] = uq[q] = du[q] = T(0);
+                if (i < T1) {
+                    load_u(Ub, i, ub);
+                    load_u(UQp, i, uq);
+                    if (pass == 0) {
+#pragma unroll
+                        for (int r = 0; r < NU; ++r) {
+                            T s = kp[(size_t)(i * NU + r) * TILE];
+#pragma unroll
+                            for (int q = 0; q < NX; ++q) s += Kp[(size_t)((i * NU + r) * NX + q) * TILE] * dx[q];
+                            du[r] = s;
+                            if (!done) DUp[(size_t)(i * NU + r) * TILE] = s;
+                            const T m = fabs_(s);
+                            dumax = m > dumax ? m : dumax;
+                        }
+                    } else {
+                        load_u(DUp, i, du);
+                    }
+                }
+                Rows rows;
+                rows.setup(p, i, T1, xb, Cp[(size_t)(i * 2) * TILE], Cp[(size_t)(i * 2 + 1) * TILE], Dp[(size_t)i * TILE], fixed0);
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    if (!rows.live[j]) continue;
+                    const T s = Sp[(size_t)(i * NR + j) * TILE], lam = Lp[(size_t)(i * NR + j) * TILE];
+                    const T rp = rows.value(j, xq, uq) + s - rows.bnd[j];
+                    const T rc = s * lam - sigma * mu;
+                    const T ds = -rp - rows.along(j, dx, du);
+                    const T dl = (-rc - lam * ds) / s;
+                    if (pass == 0) {
+                        if (ds < T(0)) {
+                            const T lim = -s / ds;
+                            amax = lim < amax ? lim : amax;
+                        }
+                        if (dl < T(0)) {
+                            const T lim = -lam / dl;
+                            amax = lim < amax ? lim : amax;
+                        }
+                    } else {
+                        const T sn = s + alpha * ds, ln2 = lam + alpha * dl;
+                        gap += sn * ln2;
+                        const T r1 = fabs_(rp) * (T(1) - alpha);
+                        rpmax = r1 > rpmax ? r1 : rpmax;
+                        if (!done) {
+                            Sp[(size_t)(i * NR + j) * TILE] = sn;
+                            Lp[(size_t)(i * NR + j) * TILE] = ln2;
+                        }
+                    }
+                }
+                if (pass == 1 && !done) {
+#pragma unroll
+                    for (int q = 0; q < NX; ++q) XQp[(size_t)(i * NX + q) * TILE] = x[q];
+                }
+                if (i < T1) {
+                    load_x(Xb, i + 1, xbn);
+                    T A[NX][NX], Bm[NX][NU], c[NX];
+                    sqp_linearise<T, M>(p, i, xb, ub, xbn, A, Bm, c);
+                    T un[NU], dxn[NX], xn[NX];
+#pragma unroll
+                    for (int q = 0; q < NU; ++q) un[q] = uq[q] + alpha * du[q];
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) {
+                        T s = T(0), t = c[r];
+#pragma unroll
+                        for (int q = 0; q < NX; ++q) {
+                            s += A[r][q] * dx[q];
+                            t += A[r][q] * x[q];
+                        }
+#pragma unroll
+                        for (int q = 0; q < NU; ++q) {
+                            s += Bm[r][q] * du[q];
+                            t += Bm[r][q] * un[q];
+                        }
+                        dxn[r] = s;
+                        xn[r] = t;
+                    }
+                    if (pass == 1 && !done) {
+#pragma unroll
+                        for (int q = 0; q < NU; ++q) UQp[(size_t)(i * NU + q) * TILE] = un[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < NX; ++q) {
+                        dx[q] = dxn[q];
+                        x[q] = xn[q];
+                        xb[q] = xbn[q];
+                    }
+                }
+            }
+        }
+        if (!done) {
+            mu = nlive > 0 ? gap / (T)nlive : T(0);
+            const bool finite = fabs_(mu) < inf_<T>() && fabs_(dumax) < inf_<T>();
+            if (!finite) {
+                failed = true;
+                done = true;
+            } else if (mu <= tol && rpmax <= tol && dumax <= T(1e-8)) {
+                done = true;
+            }
+            if (done && a.qp_iters) a.qp_iters[b] = it + 1;
+        }
+    }
+    if (active && (!done || failed)) {
+        // no solution (infeasible rows, or the iteration limit): the step is zero, which the search
+        // below turns into `converge`; the reference would receive OSQP's failure output instead
+        if (p.status) p.status[b] |= ILQR_STATUS_QP_FAILED_;
+        if (!done && a.qp_iters) a.qp_iters[b] = a.qp_max_iter;
+        for (int i = 0; i < T1; ++i)
+#pragma unroll
+            for (int q = 0; q < NU; ++q) UQp[(size_t)(i * NU + q) * TILE] = Ub[(size_t)(i * NU + q) * TILE];
+    }
+}
+
+// Step-halving search of sqp.py:153-171 with LS step sizes of a problem on LS neighbouring lanes:
+// inputs = prev + alpha d_u, states by simulation from x0, cost as in sqp.py:44-54.  The serial
+// loop accepts the first alpha whose cost is below min_cost and gives up (converge) at the first
+// rejected alpha that is below eps or whose cost is within cost_eps of min_cost; evaluated in
+// parallel that is: the lowest accepting index wins if no lower index gives up.  Then every lane of
+// the problem rolls the winning step size out once more (same instruction sequence, same bits)
+// and its first lane stores states and inputs in place.
+template <typename T, class M, int LS>
+__global__ __launch_bounds__(64) void sqp_search_kernel(Params<T, M::NX, M::NU> p, SqpArgs a, int it) {
+    constexpr int NX = M::NX, NU = M::NU, PPW = 64 / LS;
+    const int lane = threadIdx.x, pl = lane / LS, al = lane % LS;
+    const int g = blockIdx.x * PPW + pl;
+    const bool valid = g < p.B;
+    const int b = valid ? g : p.B - 1;
+    const bool active = valid && p.converged[b] == 0;
+    if (__ballot(active) == 0ull) return;
+    const int N = p.N, T1 = N - 1, tile = b >> 6, ln = b & 63;
+    T *Xt = tile_ptr(p.X, tile, N * NX, ln);
+    T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
+    const T *Rt = tile_ptr(p.Xref, tile, N * NX, ln);
+    const T *UQp = tile_ptr((const T *)a.UQ, tile, T1 * NU, ln);
+    const T Jcur = p.J[b];
+    const T eps = (T)a.eps, cost_eps = (T)a.cost_eps;
+
+    auto rollout = [&](T alpha, bool store) -> T {
+        T x[NX], cost = T(0);
+#pragma unroll
+        for (int q = 0; q < NX; ++q) x[q] = Xt[(size_t)q * TILE];
+        bool bad = false;
+        for (int i = 0; i < T1; ++i) {
+            T u[NU], e[NX], xn[NX];
+#pragma unroll
+            for (int q = 0; q < NU; ++q) {
+                const T up = Ut[(size_t)(i * NU + q) * TILE];
+                u[q] = up + alpha * (UQp[(size_t)(i * NU + q) * TILE] - up);     // sqp.py:153, :157
+                e[q] = T(0);
+            }
+#pragma unroll
+            for (int q = 0; q < NX; ++q) e[q] = x[q] - Rt[(size_t)(i * NX + q) * TILE];
+            cost += quad_<T, NX, false>(p.Q, e) + quad_<T, NU, false>(p.R, u);  // sqp.py:47-51
+            M::template step<false>(p, i, x, u, xn, bad);                        // sqp.py:59-60
+            if (store) {
+#pragma unroll
+                for (int q = 0; q < NU; ++q) Ut[(size_t)(i * NU + q) * TILE] = u[q];
+#pragma unroll
+                for (int q = 0; q < NX; ++q) Xt[(size_t)((i + 1) * NX + q) * TILE] = xn[q];
+            }
+#pragma unroll
+            for (int q = 0; q < NX; ++q) x[q] = xn[q];
+        }
+        T e[NX];
+#pragma unroll
+        for (int q = 0; q < NX; ++q) e[q] = x[q] - Rt[(size_t)(T1 * NX + q) * TILE];
+        return cost + quad_<T, NX, false>(p.Qf, e);                              // sqp.py:52-53
+    };
+
+    int win = 0x7fffffff, stop = 0x7fffffff;
+    T win_cost = T(0);
+    for (int base = 0; base < a.n_alphas; base += LS) {
+        const int ai = base + al;
+        const T alpha = pow2_neg<T>(ai);
+        const T c = rollout(alpha, false);
+        int acc = 0x7fffffff, giveup = 0x7fffffff;
+        T acc_cost = T(0);
+        if (ai < a.n_alphas) {
+            if (c < Jcur) {
+                acc = ai;
+                acc_cost = c;
+            } else if (alpha < eps || fabs_(T(1) - c / Jcur) < cost_eps) {         // sqp.py:168
+                giveup = ai;
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < LS; off <<= 1) {
+            const int oa = __shfl_xor(acc, off), og = __shfl_xor(giveup, off);
+            const T oc = __shfl_xor(acc_cost, off);
+            if (oa < acc) {
+                acc = oa;
+                acc_cost = oc;
+            }
+            giveup = og < giveup ? og : giveup;
+        }
+        if (win == 0x7fffffff && stop == 0x7fffffff) {
+            if (acc < giveup) {
+                win = acc;
+                win_cost = acc_cost;
+            } else if (giveup != 0x7fffffff) {
+                stop = giveup;
+            }
+        }
+        if (__ballot(active && win == 0x7fffffff && stop == 0x7fffffff) == 0ull) break;
+    }
+    const bool found = active && win != 0x7fffffff;
+    if (active && al == 0) {
+        p.iters[b] += 1;
+        p.alpha_idx[b] = found ? win : -1;
+        if (found) {
+            p.J[b] = win_cost;
+            if (p.status && !(fabs_(win_cost) < inf_<T>())) p.status[b] |= ILQR_STATUS_NONFINITE_;
+        } else {
+            p.converged[b] = 1;                                                  // sqp.py:169
+        }
+        if (it < p.hist_cap) {
+            if (p.hist_cost) p.hist_cost[size_t(it) * p.hist_stride + b] = found ? win_cost : Jcur;
+            if (p.hist_alpha) p.hist_alpha[size_t(it) * p.hist_stride + b] = found ? win : -1;
+        }
+    }
+    if (__ballot(found) == 0ull) return;
+    if (found) (void)rollout(pow2_neg<T>(win), al == 0);
+}
+
+// launchers --------------------------------------------------------------------------------------
+struct SqpOps {
+    hipError_t (*init)(const HostCtx &, hipStream_t);
+    hipError_t (*qp)(const HostCtx &, const SqpArgs &, hipStream_t);
+    hipError_t (*search)(const HostCtx &, const SqpArgs &, int it, hipStream_t);
+};
+
+template <typename T, template <typename> class MT> struct SqpLaunch {
+    using M = MT<T>;
+    static constexpr int NX = M::NX, NU = M::NU;
+    static Params<T, NX, NU> params(const HostCtx &c) {
+        auto p = make_params<T, NX, NU>(c);
+        // the QP bounds the inputs by umin / umax = the system's limits, or nothing (sqp.py:38-42)
+        for (int i = 0; i < NU; ++i) {
+            p.qlo[i] = c.d.control_limited ? (T)c.d.lo[i] : -std::numeric_limits<T>::infinity();
+            p.qhi[i] = c.d.control_limited ? (T)c.d.hi[i] : std::numeric_limits<T>::infinity();
+        }
+        return p;
+    }
+    static hipError_t init(const HostCtx &c, hipStream_t s) {
+        hipLaunchKernelGGL(sqp_init_kernel<T>, dim3((c.d.B + 63) / 64), dim3(64), 0, s, (T *)c.b.J, c.b.converged, c.b.iters, c.b.alpha_idx, c.d.B);
+        return hipGetLastError();
+    }
+    static hipError_t qp(const HostCtx &c, const SqpArgs &a, hipStream_t s) {
+        hipLaunchKernelGGL((sqp_qp_kernel<T, M>), dim3((c.d.B + 63) / 64), dim3(64), 0, s, params(c), a);
+        return hipGetLastError();
+    }
+    static hipError_t search(const HostCtx &c, const SqpArgs &a, int it, hipStream_t s) {
+        constexpr int LS = 8;
+        hipLaunchKernelGGL((sqp_search_kernel<T, M, LS>), dim3((c.d.B + 64 / LS - 1) / (64 / LS)), dim3(64), 0, s, params(c), a, it);
+        return hipGetLastError();
+    }
+    static const SqpOps *table() {
+        static const SqpOps ops = {&init, &qp, &search};
+        return &ops;
+    }
+};
+
+// the sequential-QP kernels of the Car model, fp64 (ops_sqp.hip); nullptr otherwise
+const SqpOps *sqp_ops(int model, int dtype);
+
+} // namespace ilqr

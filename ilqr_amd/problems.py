@@ -329,3 +329,52 @@ def pendulum_batch(B, N=120, seed0=987, first=0):
     init_states = np.zeros_like(tg)
     init_states[:, 0] = x0
     return dict(target_states=tg, init_inputs=ui, x0=x0, init_states=init_states)
+
+
+# ---- problems of the sequential-QP demo (sqp_demo.py:12-53) ---------------------------------
+SQP_Q = np.diag([50.0, 50.0, 10.0, 1.0])
+SQP_R = np.diag([300.0, 1000.0])
+SQP_LIMITS = ([-1.0, -0.3], [1.0, 0.3])
+
+
+def demo_sqp(horizon=80, seed=0, noisy=0.5, curv=0.1, radius=0.6):
+    """Problem of ``sqp_demo.py:12-53`` (``random_example``) with ``random.seed(seed)``: unit-speed arc,
+    noisy targets, bubbles of the given radius centred on the noisy targets, speed bounds [0, 2].
+    Returns (noisy_targets, init_inputs, centers, radius, vel_bounds)."""
+    rnd = _pyrandom.Random(seed)
+    target = np.zeros((horizon, 4))
+    noisy_t = np.zeros((horizon, 4))
+    noisy_t[0, 2] = target[0, 2] = 1
+    centers = np.zeros((horizon, 2))
+    ref_vel = np.ones(horizon)
+    dt = 0.2
+    for i in range(1, horizon):
+        target[i, 0] = target[i - 1, 0] + np.cos(target[i - 1, 3]) * dt * ref_vel[i - 1]
+        target[i, 1] = target[i - 1, 1] + np.sin(target[i - 1, 3]) * dt * ref_vel[i - 1]
+        target[i, 2] = ref_vel[i]
+        target[i, 3] = target[i - 1, 3] + curv * dt
+        noisy_t[i, 0] = target[i, 0] + rnd.uniform(0, noisy)
+        noisy_t[i, 1] = target[i, 1] + rnd.uniform(0, noisy)
+        noisy_t[i, 2] = ref_vel[i]
+        noisy_t[i, 3] = target[i, 3] + rnd.uniform(0, 0.1)
+        centers[i, 0], centers[i, 1] = noisy_t[i, 0], noisy_t[i, 1]
+    init_inputs = np.zeros((horizon - 1, 2))
+    for i in range(1, horizon):
+        init_inputs[i - 1, 0] = (noisy_t[i, 2] - noisy_t[i - 1, 2]) / dt
+        init_inputs[i - 1, 1] = (noisy_t[i, 3] - noisy_t[i - 1, 3]) / dt
+    return noisy_t, init_inputs, centers, np.full(horizon, float(radius)), (0.0, 2.0)
+
+
+def sqp_batch(B, N=80, seed0=2468, first=0):
+    """``B`` problems of the ``sqp_demo.py`` kind; problem ``b`` depends on ``seed0 + first + b`` only
+    (own curvature, noise level and bubble radius)."""
+    tg = np.zeros((B, N, 4))
+    ui = np.zeros((B, N - 1, 2))
+    centers = np.zeros((B, N, 2))
+    radius = np.zeros((B, N))
+    for b in range(B):
+        rng = np.random.Generator(np.random.PCG64(seed0 + first + b))
+        t, u, c, r, vb = demo_sqp(N, seed=int(rng.integers(1 << 30)), noisy=rng.uniform(0.2, 0.6),
+                                  curv=rng.uniform(-0.2, 0.2), radius=rng.uniform(0.5, 0.9))
+        tg[b], ui[b], centers[b], radius[b] = t, u, c, r
+    return dict(target_states=tg, init_inputs=ui, centers=centers, radius=radius, vel_bounds=(0.0, 2.0))

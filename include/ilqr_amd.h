@@ -72,6 +72,7 @@ typedef enum ilqr_dtype { ILQR_F64 = 0, ILQR_F32 = 1 } ilqr_dtype;
 #define ILQR_STATUS_NONPD 1   /* a Quu was not positive definite; solved by pivoted LU like numpy.linalg.inv */
 #define ILQR_STATUS_SINGULAR 2 /* a Quu was exactly singular (ilqr.py:99 would raise LinAlgError) */
 #define ILQR_STATUS_NONFINITE 4 /* the accepted cost is not finite */
+#define ILQR_STATUS_QP_FAILED 8 /* sequential QP: a QP subproblem had no solution (infeasible rows) or hit the iteration limit */
 
 typedef struct ilqr_desc {
     int32_t B;               /* problems in this handle (this GPU's shard) */
@@ -212,6 +213,44 @@ int ilqr_model_dims(int32_t model, int32_t *n, int32_t *m);
  * pointers.  For checking a device model against its host statement; not on the solve path. */
 int ilqr_model_probe(int32_t model, int32_t dtype, double dt, int32_t t, const void *params_a, const void *params_b, const void *x,
                      const void *u, void *x_next, void *fx, void *fu, int32_t count, void *stream);
+
+/* ---- sequential QP (sqp.py) -------------------------------------------------------------------
+ * The reference's second solver: per iteration the dynamics are linearised around the current
+ * trajectory, a QP over all states and inputs (sqp.py:77-134: tracking cost, linearised dynamics,
+ * the linearised rows of constraints.py:32-48, input bounds) gives new inputs, and a step-halving
+ * search on the simulated cost accepts a step towards them (sqp.py:136-171).  Batched here with one
+ * lane per problem.  The reference hands the QP to the OSQP package; this library solves it with a
+ * primal-dual interior-point iteration whose Newton step is a Riccati recursion (to qp_tol, far
+ * below OSQP's default 1e-3).
+ *
+ * Needs a handle created for ILQR_MODEL_CAR, ILQR_F64 with ILQR_CONSTR_BARRIER set in
+ * constraint_mode (so that centers and radius are bound; barrier_mu / barrier_delta are not used)
+ * and vel_bounds filled; control_limited selects whether the QP bounds the inputs (sqp.py:38-42).
+ * Before the call: X = target_states (sqp.py:138; its first row is x0, sqp.py:37), U = initial
+ * inputs.  After it: X, U, J (min_cost), converged, iters, alpha_idx, status, history as for
+ * ilqr_solve.  K and k are used as scratch.  `work` is ilqr_sqp_workspace_bytes() of device memory;
+ * u0 (tiled, rows = m) is the fixed first input when init_input_fixed != 0 (sqp.py:111-112), else
+ * NULL; qp_iters (optional, [B]) receives the iteration count of each problem's last QP. */
+typedef struct ilqr_sqp_opts {
+    int32_t max_iter;          /* sqp.py:29 (20) */
+    int32_t init_input_fixed;  /* sqp.py:36 */
+    int32_t qp_max_iter;       /* interior-point iterations per QP; 0 = 200 */
+    int32_t reserved;
+    double eps;                /* sqp.py:31 (1e-2): smallest step size tried */
+    double cost_eps;           /* sqp.py:32 (1e-6): relative cost change that ends the search */
+    double qp_tol;             /* complementarity and row residual at which a QP counts as solved; 0 = 1e-10 */
+    double qp_sigma;           /* centring parameter of the path-following iteration; 0 = 0.2 */
+} ilqr_sqp_opts;
+size_t ilqr_sqp_workspace_bytes(const ilqr_handle *h);
+int ilqr_sqp_solve(ilqr_handle *h, const ilqr_sqp_opts *opts, void *work, const void *u0, int32_t *qp_iters, void *stream);
+/* the two phases of one iteration, for callers that time or check them apart: ilqr_sqp_begin
+ * (min_cost = inf, converge = False), then per iteration ilqr_sqp_qp (the solved inputs are left in
+ * `work`, see ilqr_sqp_solved_inputs) and ilqr_sqp_search */
+int ilqr_sqp_begin(ilqr_handle *h, void *stream);
+int ilqr_sqp_qp(ilqr_handle *h, const ilqr_sqp_opts *opts, void *work, const void *u0, int32_t *qp_iters, void *stream);
+int ilqr_sqp_search(ilqr_handle *h, const ilqr_sqp_opts *opts, void *work, int32_t iteration, void *stream);
+/* device pointer (inside work) of the inputs the last ilqr_sqp_qp solved for: tiled, rows = (N-1)*m */
+void *ilqr_sqp_solved_inputs(const ilqr_handle *h, void *work);
 
 /* layout helpers: reference layout [B][rows] (what numpy holds, e.g. states (B, N, n)
  * flattened) <-> tiled device layout [ceil(B/64)][rows][64]; elem_bytes 4 or 8; both

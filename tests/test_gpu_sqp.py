@@ -1,0 +1,133 @@
+"""GPU tests of the batched sequential-QP solver (ilqr_amd/sqp.py, csrc/sqp.hpp) against the numpy
+oracle (oracle/sqp_oracle.py).  PARITY UNPINNED towards the reference (its QP solver, the OSQP
+package, is absent); towards the oracle: per-iteration cost 1e-9, equal accepted steps wherever
+the accepted decrease is above round-off, solved QP inputs 1e-8 against the same method in numpy
+and 1e-4 against the dense interior-point solver."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import noise_floor_mask
+from test_sqp_cpu import CASES, sqp_car
+
+pytestmark = pytest.mark.gpu
+
+
+def _solver(car, centers, radius, vb, targets, inputs, **kw):
+    from ilqr_amd.constraints import BubbleConstraint
+    from ilqr_amd.sqp import sequential_QP_optimizer
+    con = BubbleConstraint(targets.shape[-2])
+    con.setup(centers, radius, vb)
+    opt = sequential_QP_optimizer(car, con, targets, 0.2, history=True, **kw)
+    opt.set_init_inputs(np.array(inputs))
+    return opt, con
+
+
+def _check_against_oracle(opt_cost, opt_alpha, opt_iters, r, tol=1e-9):
+    n = min(int(opt_iters), r["iters"])
+    assert n >= r["iters"] - 3
+    rel = np.abs(opt_cost[:n] - r["hist_cost"][:n]) / np.abs(r["hist_cost"][:n])
+    assert rel.max() <= tol, rel
+    solid = noise_floor_mask(r["hist_cost"][:n], np.inf, rel=1e-10)
+    assert np.array_equal(opt_alpha[:n][solid], r["hist_alpha"][:n][solid])
+    return n
+
+
+def test_single_problem_like_the_demo(oracle):
+    """sqp_demo.py:12-58 with a seeded random stream, one problem, the reference's call sequence."""
+    from oracle import sqp_oracle as so
+    from ilqr_amd import problems
+    tg, ui, c, r, vb = problems.demo_sqp(80, 0)
+    car = sqp_car(80)
+    opt, con = _solver(car, c, r, vb, tg, ui)
+    out = opt()
+    assert out is opt.states and out.shape == (80, 4) and isinstance(opt.min_cost, float)
+    ref = so.sqp_solve(car, con, tg, ui, qp="riccati")
+    _check_against_oracle(opt.cost_history, opt.alpha_history, opt.iterations, ref)
+    assert opt.converge == ref["converge"] and opt.status == 0
+    assert np.abs(opt.states - ref["states"]).max() <= 1e-7 and np.abs(opt.inputs - ref["inputs"]).max() <= 1e-7
+    assert np.allclose(so.sim(car, tg[0], opt.inputs), opt.states, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("seed,rad,vb,lim", CASES)
+def test_first_qp_matches_both_oracle_solvers(seed, rad, vb, lim):
+    """One ilqr_sqp_qp call through the C ABI: the solved inputs against the numpy statement of the
+    same method and against the dense interior-point solver."""
+    import torch
+    from oracle import sqp_oracle as so
+    from ilqr_amd import _lib, problems
+    N = 60
+    tg, ui, c, r, _ = problems.demo_sqp(N, seed, radius=rad)
+    car = sqp_car(N, lim)
+    for fixed in (False, True):
+        opt, con = _solver(car, c, r, vb, tg, ui)
+        if fixed:
+            opt.init_input_fixed = True
+            opt.u0 = ui[0] + 0.01
+        dev = opt.upload()
+        o = opt._opts()
+        lib = dev.lib
+        _lib.check(lib.ilqr_sqp_begin(dev.handle, dev.stream()), "begin")
+        _lib.check(lib.ilqr_sqp_qp(dev.handle, C.byref(o), opt._work.data_ptr(), opt._u0.data_ptr(), opt._qp_iters.data_ptr(),
+                                   dev.stream()), "qp")
+        uq = torch.zeros(64 * (N - 1) * 2, dtype=torch.float64, device="cuda")
+        ptr = lib.ilqr_sqp_solved_inputs(dev.handle, opt._work.data_ptr())
+        out = torch.empty((N - 1) * 2, dtype=torch.float64, device="cuda")
+        _lib.check(lib.ilqr_from_tiled(ptr, out.data_ptr(), 1, (N - 1) * 2, 8, dev.stream()), "from_tiled")
+        u_gpu = out.cpu().numpy().reshape(N - 1, 2)
+        del uq
+        A, B, cc, G, lo, hi = so.qp_data(car, con, tg, tg.copy(), ui)
+        umin, umax = np.array(lim[0], float), np.array(lim[1], float)
+        u0 = opt.u0 if fixed else None
+        u_r, _, its = so.solve_qp_riccati(car, tg, tg[0], A, B, cc, G, lo, hi, umin, umax, ui, u0=u0)
+        u_d, _ = so.solve_qp(car, tg, tg[0], A, B, cc, G, lo, hi, umin, umax, u0=u0)
+        assert int(opt._qp_iters.cpu()[0]) == its
+        assert np.abs(u_gpu - u_r).max() <= 1e-8
+        assert np.abs(u_gpu - u_d).max() <= 1e-4
+        assert int(dev.status.cpu()[0]) == 0
+
+
+def test_batch_matches_oracle_and_does_not_depend_on_sharding():
+    from oracle import sqp_oracle as so
+    from ilqr_amd import problems
+    from ilqr_amd.constraints import BubbleConstraint
+    B, N = 100, 80
+    p = problems.sqp_batch(B, N)
+    car = sqp_car(N)
+    opt, _ = _solver(car, p["centers"], p["radius"], p["vel_bounds"], p["target_states"], p["init_inputs"])
+    opt()
+    assert opt.states.shape == (B, N, 4) and opt.min_cost.shape == (B,)
+    ok = opt.status == 0
+    assert ok.mean() > 0.8
+    for b in np.flatnonzero(ok)[:10]:
+        con = BubbleConstraint(N)
+        con.setup(p["centers"][b], p["radius"][b], p["vel_bounds"])
+        ref = so.sqp_solve(car, con, p["target_states"][b], p["init_inputs"][b], qp="riccati")
+        _check_against_oracle(opt.cost_history[b], opt.alpha_history[b], opt.iterations[b], ref)
+    # problems whose linearised rows cannot be met are flagged, stop, and keep a valid trajectory
+    bad = ~ok
+    assert np.all(opt.status[bad] == 8) and np.all(opt.converge[bad]) and np.all(np.isfinite(opt.states))
+    # shard invariance: two halves (ragged against the 64-problem tiles) give the same bits
+    parts = []
+    for sl in (slice(0, 37), slice(37, B)):
+        o, _ = _solver(car, p["centers"][sl], p["radius"][sl], p["vel_bounds"], p["target_states"][sl], p["init_inputs"][sl])
+        o()
+        parts.append(o)
+    assert np.array_equal(np.concatenate([o.states for o in parts]), opt.states)
+    assert np.array_equal(np.concatenate([o.min_cost for o in parts]), opt.min_cost)
+    assert np.array_equal(np.concatenate([o.iterations for o in parts]), opt.iterations)
+
+
+def test_inputs_without_limits_and_iteration_budget():
+    """control_limited = False: the QP has no input rows (sqp.py:38-39); maxIter is honoured."""
+    from oracle import sqp_oracle as so
+    from ilqr_amd import problems
+    tg, ui, c, r, vb = problems.demo_sqp(60, 4)
+    car = sqp_car(60, limits=None)
+    opt, con = _solver(car, c, r, vb, tg, ui)
+    opt.maxIter = 2
+    opt()
+    ref = so.sqp_solve(car, con, tg, ui, max_iter=2, qp="riccati")
+    assert opt.iterations == 2 == ref["iters"] and not opt.converge
+    assert np.abs(opt.cost_history[:2] - ref["hist_cost"]).max() <= 1e-9 * ref["hist_cost"].max()
