@@ -715,7 +715,7 @@ int sqp_args(const ilqr_handle *h, const ilqr_sqp_opts *o, void *work, const voi
     a.eps = o->eps;
     a.cost_eps = o->cost_eps;
     a.qp_tol = o->qp_tol > 0.0 ? o->qp_tol : 1e-10;
-    a.qp_sigma = o->qp_sigma > 0.0 ? o->qp_sigma : 0.2;
+    a.qp_sigma = o->qp_sigma > 0.0 ? o->qp_sigma : 0.1;
     a.qp_max_iter = o->qp_max_iter > 0 ? o->qp_max_iter : 200;
     a.n_alphas = alphas_from_floor(o->eps); // the step sizes the loop of sqp.py:156-171 can visit
     a.fixed = o->init_input_fixed ? 1 : 0;

@@ -9,6 +9,8 @@
 //                      solved by a primal-dual path-following iteration whose Newton step is an
 //                      LQR problem (all inequality rows act on one time step), solved exactly by
 //                      a Riccati recursion: three sweeps over the horizon per iteration.
+//                      Jacobian entries a model declares structurally zero or one are skipped at
+//                      compile time (adding an exact zero changes no bit).
 //   sqp_search_kernel  sqp.py:149-171   the step-halving search on the simulated cost, all step
 //                      sizes of a problem on neighbouring lanes, and the accepted step written
 //                      in place.
@@ -81,14 +83,17 @@ __device__ __forceinline__ void sqp_linearise(const P &p, int i, const T (&xb)[M
         for (int b = 0; b < NU; ++b) B[a][b] = T(0);
     }
     bool bad = false;
-    M::template jac<false>(p, i, xb, ub, A, B, bad);
+    M::template jac<true>(p, i, xb, ub, A, B, bad);
+    if (bad) M::template jac<false>(p, i, xb, ub, A, B, bad); // an angle outside the fast routine's range
 #pragma unroll
     for (int a = 0; a < NX; ++a) {
         T s = xbn[a];
 #pragma unroll
-        for (int b = 0; b < NX; ++b) s -= A[a][b] * xb[b];
+        for (int b = 0; b < NX; ++b)
+            if (M::fx_nz(a, b)) s -= M::fx_one(a, b) ? xb[b] : A[a][b] * xb[b];
 #pragma unroll
-        for (int b = 0; b < NU; ++b) s -= B[a][b] * ub[b];
+        for (int b = 0; b < NU; ++b)
+            if (M::fu_nz(a, b)) s -= B[a][b] * ub[b];
         c[a] = s;
     }
 }
@@ -185,9 +190,11 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                 for (int r = 0; r < NX; ++r) {
                     T s = c[r];
 #pragma unroll
-                    for (int q = 0; q < NX; ++q) s += A[r][q] * x[q];
+                    for (int q = 0; q < NX; ++q)
+                        if (M::fx_nz(r, q)) s += M::fx_one(r, q) ? x[q] : A[r][q] * x[q];
 #pragma unroll
-                    for (int q = 0; q < NU; ++q) s += Bm[r][q] * u[q];
+                    for (int q = 0; q < NU; ++q)
+                        if (M::fu_nz(r, q)) s += Bm[r][q] * u[q];
                     xn[r] = s;
                 }
 #pragma unroll
@@ -292,14 +299,16 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                         for (int q = 0; q < NX; ++q) {
                             T s = T(0);
 #pragma unroll
-                            for (int w = 0; w < NX; ++w) s += Pm[r][w] * A[w][q];
+                            for (int w = 0; w < NX; ++w)
+                                if (M::fx_nz(w, q)) s += M::fx_one(w, q) ? Pm[r][w] : Pm[r][w] * A[w][q];
                             PA[r][q] = s;
                         }
 #pragma unroll
                         for (int q = 0; q < NU; ++q) {
                             T s = T(0);
 #pragma unroll
-                            for (int w = 0; w < NX; ++w) s += Pm[r][w] * Bm[w][q];
+                            for (int w = 0; w < NX; ++w)
+                                if (M::fu_nz(w, q)) s += Pm[r][w] * Bm[w][q];
                             PB[r][q] = s;
                         }
                     }
@@ -308,13 +317,15 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                     for (int r = 0; r < NX; ++r) {
                         T s = gxv[r];
 #pragma unroll
-                        for (int w = 0; w < NX; ++w) s += A[w][r] * pv[w];
+                        for (int w = 0; w < NX; ++w)
+                            if (M::fx_nz(w, r)) s += M::fx_one(w, r) ? pv[w] : A[w][r] * pv[w];
                         Qx[r] = s;
 #pragma unroll
                         for (int q = 0; q < NX; ++q) {
                             T t = Hx[r][q];
 #pragma unroll
-                            for (int w = 0; w < NX; ++w) t += A[w][r] * PA[w][q];
+                            for (int w = 0; w < NX; ++w)
+                                if (M::fx_nz(w, r)) t += M::fx_one(w, r) ? PA[w][q] : A[w][r] * PA[w][q];
                             Qxx[r][q] = t;
                         }
                     }
@@ -322,20 +333,23 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                     for (int r = 0; r < NU; ++r) {
                         T s = guv[r];
 #pragma unroll
-                        for (int w = 0; w < NX; ++w) s += Bm[w][r] * pv[w];
+                        for (int w = 0; w < NX; ++w)
+                            if (M::fu_nz(w, r)) s += Bm[w][r] * pv[w];
                         Qu[r] = s;
 #pragma unroll
                         for (int q = 0; q < NX; ++q) {
                             T t = T(0);
 #pragma unroll
-                            for (int w = 0; w < NX; ++w) t += Bm[w][r] * PA[w][q];
+                            for (int w = 0; w < NX; ++w)
+                                if (M::fu_nz(w, r)) t += Bm[w][r] * PA[w][q];
                             Qux[r][q] = t;
                         }
 #pragma unroll
                         for (int q = 0; q < NU; ++q) {
                             T t = Hu[r][q];
 #pragma unroll
-                            for (int w = 0; w < NX; ++w) t += Bm[w][r] * PB[w][q];
+                            for (int w = 0; w < NX; ++w)
+                                if (M::fu_nz(w, r)) t += Bm[w][r] * PB[w][q];
                             Quu[r][q] = t;
                         }
                     }
@@ -382,7 +396,7 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
             failed = failed || bad;
         }
         // ---- forward sweeps: 0 = direction and step length, 1 = apply and measure
-        T amax = T(1), alpha = T(0), gap = T(0), rpmax = T(0), dumax = T(0);
+        T amax = T(1), dmax = T(1), alpha = T(0), alphad = T(0), gap = T(0), rpmax = T(0), dumax = T(0);
         for (int pass = 0; pass < 2; ++pass) {
             T dx[NX], x[NX], xb[NX], xbn[NX];
             load_x(Xb, 0, xb);
@@ -392,8 +406,10 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                 x[q] = xb[q];
             }
             if (pass == 1) {
-                const T am = T(0.995) * amax;
+                // separate step lengths: alpha for inputs, states and slacks, alphad for the multipliers
+                const T am = T(0.995) * amax, dm = T(0.995) * dmax;
                 alpha = am < T(1) ? am : T(1);
+                alphad = dm < T(1) ? dm : T(1);
             }
             for (int i = 0; i < N; ++i) {
                 T ub[NU], uq[NU], xq[NX], du[NU];
@@ -435,10 +451,10 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                         }
                         if (dl < T(0)) {
                             const T lim = -lam / dl;
-                            amax = lim < amax ? lim : amax;
+                            dmax = lim < dmax ? lim : dmax;
                         }
                     } else {
-                        const T sn = s + alpha * ds, ln2 = lam + alpha * dl;
+                        const T sn = s + alpha * ds, ln2 = lam + alphad * dl;
                         gap += sn * ln2;
                         const T r1 = fabs_(rp) * (T(1) - alpha);
                         rpmax = r1 > rpmax ? r1 : rpmax;
@@ -463,15 +479,17 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                     for (int r = 0; r < NX; ++r) {
                         T s = T(0), t = c[r];
 #pragma unroll
-                        for (int q = 0; q < NX; ++q) {
-                            s += A[r][q] * dx[q];
-                            t += A[r][q] * x[q];
-                        }
+                        for (int q = 0; q < NX; ++q)
+                            if (M::fx_nz(r, q)) {
+                                s += M::fx_one(r, q) ? dx[q] : A[r][q] * dx[q];
+                                t += M::fx_one(r, q) ? x[q] : A[r][q] * x[q];
+                            }
 #pragma unroll
-                        for (int q = 0; q < NU; ++q) {
-                            s += Bm[r][q] * du[q];
-                            t += Bm[r][q] * un[q];
-                        }
+                        for (int q = 0; q < NU; ++q)
+                            if (M::fu_nz(r, q)) {
+                                s += Bm[r][q] * du[q];
+                                t += Bm[r][q] * un[q];
+                            }
                         dxn[r] = s;
                         xn[r] = t;
                     }
@@ -491,7 +509,9 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
         if (!done) {
             mu = nlive > 0 ? gap / (T)nlive : T(0);
             const bool finite = fabs_(mu) < inf_<T>() && fabs_(dumax) < inf_<T>();
-            if (!finite) {
+            // a step length that collapses means the rows cannot all be met (the multipliers of an
+            // infeasible set of rows grow without bound while the slacks stall)
+            if (!finite || alpha < T(1e-8) || alphad < T(1e-8)) {
                 failed = true;
                 done = true;
             } else if (mu <= tol && rpmax <= tol && dumax <= T(1e-8)) {

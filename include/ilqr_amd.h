@@ -239,7 +239,7 @@ typedef struct ilqr_sqp_opts {
     double eps;                /* sqp.py:31 (1e-2): smallest step size tried */
     double cost_eps;           /* sqp.py:32 (1e-6): relative cost change that ends the search */
     double qp_tol;             /* complementarity and row residual at which a QP counts as solved; 0 = 1e-10 */
-    double qp_sigma;           /* centring parameter of the path-following iteration; 0 = 0.2 */
+    double qp_sigma;           /* centring parameter of the path-following iteration; 0 = 0.1 */
 } ilqr_sqp_opts;
 size_t ilqr_sqp_workspace_bytes(const ilqr_handle *h);
 int ilqr_sqp_solve(ilqr_handle *h, const ilqr_sqp_opts *opts, void *work, const void *u0, int32_t *qp_iters, void *stream);

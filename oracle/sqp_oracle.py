@@ -220,14 +220,14 @@ def sqp_solve(system, constraint, target, init_inputs, max_iter=20, eps=1e-2, co
     return out
 
 
-def solve_qp_riccati(system, target, x0, A, B, c, G, lo, hi, umin, umax, u_start, u0=None, sigma=0.2, tol=1e-10,
+def solve_qp_riccati(system, target, x0, A, B, c, G, lo, hi, umin, umax, u_start, u0=None, sigma=0.1, tol=1e-10,
                      max_iter=100, info=None):
     """Same QP as solve_qp(), by the method of the GPU kernel (sqp_qp_kernel): the rows are
     r_j' z <= h_j with slacks s_j > 0 and multipliers lam_j > 0; per iteration
       backward sweep: Riccati recursion of  min 1/2 dz' (H + R' diag(lam/s) R) dz + g~' dz  over the
                       linearised dynamics dx+ = A dx + B du, dx_0 = 0, with
                       g~ = H z + g + R' (lam + (lam rp - rc) / s),  rp = R z + s - h,  rc = s lam - sigma mu;
-      forward sweep 1: dz by rollout, ds = -rp - R dz, dlam = (-rc - lam ds) / s, largest step that keeps
+      forward sweep 1: dz by rollout, ds = -rp - R dz, dlam = (-rc - lam ds) / s, largest steps that keep
                       s and lam positive;
       forward sweep 2: the step is applied and mu, |rp| of the new point are measured.
     Rows of a step, in this order: bubble upper, speed lower, speed upper (steps 1..N-1), then per
@@ -325,7 +325,7 @@ def solve_qp_riccati(system, target, x0, A, B, c, G, lo, hi, umin, umax, u_start
         # forward sweep 1: direction and step length
         dx = np.zeros(n)
         du = np.zeros((T, m))
-        a_max = 1.0
+        a_max = d_max = 1.0
         for i in range(N):
             if i < T:
                 du[i] = K[i] @ dx + kf[i]
@@ -339,10 +339,12 @@ def solve_qp_riccati(system, target, x0, A, B, c, G, lo, hi, umin, umax, u_start
                 if ds < 0:
                     a_max = min(a_max, -s[i, j] / ds)
                 if dl < 0:
-                    a_max = min(a_max, -lam[i, j] / dl)
+                    d_max = min(d_max, -lam[i, j] / dl)
             if i < T:
                 dx = A[i] @ dx + B[i] @ du[i]
+        # separate step lengths: `a` for inputs, states and slacks, `ad` for the multipliers
         a = min(1.0, 0.995 * a_max)
+        ad = min(1.0, 0.995 * d_max)
         # forward sweep 2: apply, measure
         dx = np.zeros(n)
         x = np.array(x0, float)
@@ -358,7 +360,7 @@ def solve_qp_riccati(system, target, x0, A, B, c, G, lo, hi, umin, umax, u_start
                 ds = -rp - (gx @ dx if gx is not None else gu @ du[i])
                 dl = (-rc - lam[i, j] * ds) / s[i, j]
                 s[i, j] += a * ds
-                lam[i, j] += a * dl
+                lam[i, j] += ad * dl
                 gap += s[i, j] * lam[i, j]
                 rp_max = max(rp_max, abs(rp) * (1.0 - a))
             xs[i] = x
@@ -370,7 +372,7 @@ def solve_qp_riccati(system, target, x0, A, B, c, G, lo, hi, umin, umax, u_start
         step = np.abs(du).max() * a
         if info is not None:
             info.append((it, a, mu, rp_max, step))
-        if not np.isfinite(mu):
+        if not np.isfinite(mu) or min(a, ad) < 1e-8:   # no solution: the step length collapses when the rows are infeasible
             break
         if mu <= tol and rp_max <= tol and np.abs(du).max() <= 1e-8:
             break

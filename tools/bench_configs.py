@@ -57,6 +57,20 @@ def build(name):
         opt = iterative_LQR(s, p["target_states"], 0.05, dtype=np.float32 if name.endswith("f32") else np.float64)
         opt.inputs, opt.states = p["init_inputs"], p["init_states"]
         return opt, f"LTV n=12 m=4, B={B}, N={N}, maxIter=30, {'fp32' if name.endswith('f32') else 'fp64'}"
+    if name == "sqp16384":
+        from ilqr_amd.sqp import sequential_QP_optimizer
+        B, N = 16384, 80
+        p = problems.sqp_batch(B, N)
+        car = systems.Car()
+        car.set_dt(0.2)
+        car.set_cost(problems.SQP_Q.copy(), problems.SQP_R.copy())
+        car.Q_f = car.Q * N / 100
+        car.set_control_limit(*problems.SQP_LIMITS)
+        con = BubbleConstraint(N)
+        con.setup(p["centers"], p["radius"], p["vel_bounds"])
+        opt = sequential_QP_optimizer(car, con, p["target_states"], 0.2)
+        opt.set_init_inputs(p["init_inputs"])
+        return opt, f"sqp: Car, bubbles + speed box + input box, B={B}, N={N}, maxIter=20, fp64"
     raise SystemExit(f"unknown configuration {name}")
 
 
