@@ -141,6 +141,42 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
         for (int q = 0; q < NU; ++q) u[q] = base[(size_t)(i * NU + q) * TILE];
     };
 
+    // Everything a sweep reads of one time step.  Each sweep fetches the record of the step after the
+    // one it works on before it starts working (no store of a sweep touches another step's rows), so
+    // the memory latency of a step hides behind the arithmetic of its predecessor; with one wave per
+    // SIMD at these batch sizes nothing else would hide it.
+    struct Step {
+        T xb[NX], ub[NU], xq[NX], uq[NU], xr[NX], cx, cy, rad, s[NR], lam[NR], K[NU][NX], k[NU], du[NU];
+    };
+    // what: 0 = backward sweep, 1 = forward sweep that needs the gains, 2 = forward sweep that needs the direction
+    auto fetch = [&](int i, int what, Step &st) {
+        load_x(Xb, i, st.xb);
+        load_x(XQp, i, st.xq);
+        if (what == 0) load_x(Rt, i, st.xr);
+        st.cx = Cp[(size_t)(i * 2) * TILE];
+        st.cy = Cp[(size_t)(i * 2 + 1) * TILE];
+        st.rad = Dp[(size_t)i * TILE];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            st.s[j] = Sp[(size_t)(i * NR + j) * TILE];
+            st.lam[j] = Lp[(size_t)(i * NR + j) * TILE];
+        }
+#pragma unroll
+        for (int q = 0; q < NU; ++q) st.ub[q] = st.uq[q] = st.k[q] = st.du[q] = T(0);
+        if (i < T1) {
+            load_u(Ub, i, st.ub);
+            load_u(UQp, i, st.uq);
+            if (what == 1) {
+                load_u(kp, i, st.k);
+#pragma unroll
+                for (int r = 0; r < NU; ++r)
+#pragma unroll
+                    for (int q = 0; q < NX; ++q) st.K[r][q] = Kp[(size_t)((i * NU + r) * NX + q) * TILE];
+            }
+            if (what == 2) load_u(DUp, i, st.du);
+        }
+    };
+
     // ---- start: inputs = current inputs, states by the linearised dynamics, slacks from the rows
     T mu = T(0);
     int nlive = 0;
@@ -222,19 +258,18 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                 for (int q = 0; q < NX; ++q) Pm[r][q] = T(0);
             }
             bool bad = false;
+            Step nxt;
+            fetch(T1, 0, nxt);
             for (int i = T1; i >= 0; --i) {
-                T xb[NX], ub[NU], xq[NX], uq[NU], xr[NX];
-                load_x(Xb, i, xb);
-                load_x(XQp, i, xq);
-                load_x(Rt, i, xr);
-#pragma unroll
-                for (int q = 0; q < NU; ++q) ub[q] = uq[q] = T(0);
-                if (i < T1) {
-                    load_u(Ub, i, ub);
-                    load_u(UQp, i, uq);
-                }
+                const Step st = nxt;
+                if (i > 0) fetch(i - 1, 0, nxt);
+                const T(&xb)[NX] = st.xb;
+                const T(&ub)[NU] = st.ub;
+                const T(&xq)[NX] = st.xq;
+                const T(&uq)[NU] = st.uq;
+                const T(&xr)[NX] = st.xr;
                 Rows rows;
-                rows.setup(p, i, T1, xb, Cp[(size_t)(i * 2) * TILE], Cp[(size_t)(i * 2 + 1) * TILE], Dp[(size_t)i * TILE], fixed0);
+                rows.setup(p, i, T1, xb, st.cx, st.cy, st.rad, fixed0);
                 const T *W = i == T1 ? p.Qf : p.Q;
                 T Hx[NX][NX], gxv[NX], Hu[NU][NU], guv[NU];
 #pragma unroll
@@ -260,7 +295,7 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
                     if (!rows.live[j]) continue;
-                    const T s = Sp[(size_t)(i * NR + j) * TILE], lam = Lp[(size_t)(i * NR + j) * TILE];
+                    const T s = st.s[j], lam = st.lam[j];
                     const T rp = rows.value(j, xq, uq) + s - rows.bnd[j];
                     const T rc = s * lam - sigma * mu;
                     const T coef = lam + (lam * rp - rc) / s;
@@ -398,12 +433,13 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
         // ---- forward sweeps: 0 = direction and step length, 1 = apply and measure
         T amax = T(1), dmax = T(1), alpha = T(0), alphad = T(0), gap = T(0), rpmax = T(0), dumax = T(0);
         for (int pass = 0; pass < 2; ++pass) {
-            T dx[NX], x[NX], xb[NX], xbn[NX];
-            load_x(Xb, 0, xb);
+            T dx[NX], x[NX];
+            Step nxt;
+            fetch(0, pass + 1, nxt);
 #pragma unroll
             for (int q = 0; q < NX; ++q) {
                 dx[q] = T(0);
-                x[q] = xb[q];
+                x[q] = nxt.xb[q];
             }
             if (pass == 1) {
                 // separate step lengths: alpha for inputs, states and slacks, alphad for the multipliers
@@ -412,34 +448,33 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                 alphad = dm < T(1) ? dm : T(1);
             }
             for (int i = 0; i < N; ++i) {
-                T ub[NU], uq[NU], xq[NX], du[NU];
-                load_x(XQp, i, xq);
+                const Step st = nxt;
+                if (i < T1) fetch(i + 1, pass + 1, nxt);
+                const T(&xb)[NX] = st.xb;
+                const T(&ub)[NU] = st.ub;
+                const T(&xq)[NX] = st.xq;
+                const T(&uq)[NU] = st.uq;
+                T du[NU];
 #pragma unroll
-                for (int q = 0; q < NU; ++q) ub[q] = uq[q] = du[q] = T(0);
-                if (i < T1) {
-                    load_u(Ub, i, ub);
-                    load_u(UQp, i, uq);
-                    if (pass == 0) {
+                for (int q = 0; q < NU; ++q) du[q] = st.du[q];
+                if (i < T1 && pass == 0) {
 #pragma unroll
-                        for (int r = 0; r < NU; ++r) {
-                            T s = kp[(size_t)(i * NU + r) * TILE];
+                    for (int r = 0; r < NU; ++r) {
+                        T s = st.k[r];
 #pragma unroll
-                            for (int q = 0; q < NX; ++q) s += Kp[(size_t)((i * NU + r) * NX + q) * TILE] * dx[q];
-                            du[r] = s;
-                            if (!done) DUp[(size_t)(i * NU + r) * TILE] = s;
-                            const T m = fabs_(s);
-                            dumax = m > dumax ? m : dumax;
-                        }
-                    } else {
-                        load_u(DUp, i, du);
+                        for (int q = 0; q < NX; ++q) s += st.K[r][q] * dx[q];
+                        du[r] = s;
+                        if (!done) DUp[(size_t)(i * NU + r) * TILE] = s;
+                        const T m = fabs_(s);
+                        dumax = m > dumax ? m : dumax;
                     }
                 }
                 Rows rows;
-                rows.setup(p, i, T1, xb, Cp[(size_t)(i * 2) * TILE], Cp[(size_t)(i * 2 + 1) * TILE], Dp[(size_t)i * TILE], fixed0);
+                rows.setup(p, i, T1, xb, st.cx, st.cy, st.rad, fixed0);
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
                     if (!rows.live[j]) continue;
-                    const T s = Sp[(size_t)(i * NR + j) * TILE], lam = Lp[(size_t)(i * NR + j) * TILE];
+                    const T s = st.s[j], lam = st.lam[j];
                     const T rp = rows.value(j, xq, uq) + s - rows.bnd[j];
                     const T rc = s * lam - sigma * mu;
                     const T ds = -rp - rows.along(j, dx, du);
@@ -469,9 +504,8 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                     for (int q = 0; q < NX; ++q) XQp[(size_t)(i * NX + q) * TILE] = x[q];
                 }
                 if (i < T1) {
-                    load_x(Xb, i + 1, xbn);
                     T A[NX][NX], Bm[NX][NU], c[NX];
-                    sqp_linearise<T, M>(p, i, xb, ub, xbn, A, Bm, c);
+                    sqp_linearise<T, M>(p, i, xb, ub, nxt.xb, A, Bm, c);
                     T un[NU], dxn[NX], xn[NX];
 #pragma unroll
                     for (int q = 0; q < NU; ++q) un[q] = uq[q] + alpha * du[q];
@@ -501,7 +535,6 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                     for (int q = 0; q < NX; ++q) {
                         dx[q] = dxn[q];
                         x[q] = xn[q];
-                        xb[q] = xbn[q];
                     }
                 }
             }
