@@ -62,7 +62,10 @@ class DeviceProblem:
             else:
                 from . import trace
                 try:
-                    model_id = trace.traced_model(system, self.np_dtype, diag)
+                    # a caller that attaches constraints.py rows vouches for the (px, py, v) state layout
+                    model_id = trace.traced_model(system, self.np_dtype, diag,
+                                                  has_barrier=bool(constraint_mode & _lib.CONSTR_BARRIER)
+                                                  or bool(getattr(system, "device_has_barrier", False)))
                 except trace.TraceError as e:
                     raise _lib.IlqrError(f"{type(system).__name__} has no device dynamics and its numpy methods "
                                          f"could not be recorded: {e}") from e

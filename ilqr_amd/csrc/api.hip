@@ -692,6 +692,8 @@ const SqpOps *sqp_check(const ilqr_handle *h, int &rc) {
         return nullptr;
     }
     const SqpOps *ops = sqp_ops(h->ctx.d.model, h->ctx.d.dtype);
+    if (!ops)
+        if (const LoadedModel *lm = loaded_model(h->ctx.d.model); lm && lm->info.sqp) ops = lm->info.sqp(h->ctx.d.dtype);
     // the constraint rows need centers and radius, which a handle only demands in barrier mode
     if (!ops || !(h->ctx.d.constraint_mode & ILQR_CONSTR_BARRIER)) rc = ILQR_ERR_UNSUPPORTED;
     if (h->whole.packed) rc = ILQR_ERR_INVALID;

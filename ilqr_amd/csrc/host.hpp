@@ -102,14 +102,16 @@ struct ModelOps {
 // What a separately compiled model library (ilqr_load_model) hands to this one.  `abi` must equal
 // plugin_abi() of the loading library: both sides are compiled from the same headers, and the
 // launch tables exchange HostCtx by reference.
+struct SqpOps; // launch table of the sequential-QP kernels (sqp.hpp)
 struct PluginInfo {
     int32_t abi;
     int32_t n, m;
     int32_t has_barrier; // the state starts with (px, py, v): the barrier terms of constraints.py:20-26 apply
     int32_t needs_tables; // the dynamics read the shared tables (ilqr_buffers.ltv_A / ltv_B): they must be bound
     const ModelOps *(*ops)(int dtype, bool diag);
+    const SqpOps *(*sqp)(int dtype); // sequential-QP kernels for this model, or a function returning null
 };
-constexpr int32_t PLUGIN_ABI_VERSION = 2;
+constexpr int32_t PLUGIN_ABI_VERSION = 3;
 static inline int32_t plugin_abi() {
     return (int32_t)(PLUGIN_ABI_VERSION * 1000003u + sizeof(HostCtx) * 31u + sizeof(ilqr_desc) * 7u + sizeof(ilqr_buffers));
 }

@@ -271,11 +271,13 @@ def trace_system(system, check_points=8, seed=0):
     return dict(step=step, jac=_emit(g, jac), fx_pattern=fxp, fu_pattern=fup)
 
 
-def traced_model(system, dtype=np.float64, diag=True):
-    """Trace, compile (cached) and register the dynamics of ``system``; returns the model id."""
+def traced_model(system, dtype=np.float64, diag=True, has_barrier=False):
+    """Trace, compile (cached) and register the dynamics of ``system``; returns the model id.
+    ``has_barrier``: the state starts with (px, py, v), the layout ``constraints.py:12`` is written
+    for (needed by the barrier mode and by the sequential-QP solver)."""
     from . import jit
     t = trace_system(system)
     variant = ("f64" if np.dtype(dtype) == np.float64 else "f32", bool(diag))
     src = jit.model_source(system.state_size, system.control_size, t["step"], t["jac"], t["fx_pattern"],
-                           t["fu_pattern"], variants=(variant,))
+                           t["fu_pattern"], has_barrier=bool(has_barrier), variants=(variant,))
     return jit.load_model(jit.build_model(src))

@@ -155,3 +155,30 @@ class NumpyBicycle(System):
 
     def compute_df_du(self, x, u):
         return np.array([[0.0, 0.0], [0.0, 0.0], [0.0, 0.0], [1.0, 0.0], [0.0, 1.0]]) * self.dt
+
+
+class NumpyCar(System):
+    """The car of ``systems.py:27-57`` (state ``(px, py, v, theta)``, control ``(acc, theta rate)``)
+    stated with numpy methods only, for the recorder; its state starts with ``(px, py, v)``, so the
+    rows of ``constraints.py`` apply and the sequential-QP solver accepts it."""
+
+    device_has_barrier = True
+
+    def __init__(self):
+        super().__init__(4, 2)
+        self.dt = 0.2
+
+    def model_f(self, x, u):
+        v, theta = x[2], x[3]
+        rate = np.array([v * np.cos(theta), v * np.sin(theta), u[0], u[1]])
+        return x + rate * self.dt
+
+    def compute_df_dx(self, x, u):
+        v, theta, dt = x[2], x[3], self.dt
+        return np.array([[1.0, 0.0, np.cos(theta) * dt, -np.sin(theta) * v * dt],
+                         [0.0, 1.0, np.sin(theta) * dt, np.cos(theta) * v * dt],
+                         [0.0, 0.0, 1.0, 0.0],
+                         [0.0, 0.0, 0.0, 1.0]])
+
+    def compute_df_du(self, x, u):
+        return np.array([[0.0, 0.0], [0.0, 0.0], [self.dt, 0.0], [0.0, self.dt]])

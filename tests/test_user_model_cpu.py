@@ -42,6 +42,9 @@ def test_model_source_states_patterns_and_variants():
     # first row of fx_pattern [2, 0, 1, 1, 0]: non-zero mask and constant-one mask
     assert "tab[NX * NX] = {true, false, true, true, false," in src
     assert "tab[NX * NX] = {true, false, false, false, false," in src
+    assert "SqpLaunch" not in src.split("user_sqp")[1]          # no (px, py, v) layout declared
+    src_b = jit.model_source(5, 2, s.device_step, s.device_jac, has_barrier=True)
+    assert "SqpLaunch<double, UserModel>::table()" in src_b.split("user_sqp")[1]
     with pytest.raises(ValueError):
         jit.model_source(5, 2, "", "", fx_pattern=[[1, 0]])
     with pytest.raises(ValueError):
