@@ -661,7 +661,7 @@ int ilqr_model_probe(int32_t model, int32_t dtype, double dt, int32_t t, const v
 // ---- sequential QP (sqp.hpp) -----------------------------------------------------------------
 namespace {
 struct SqpLayout {
-    size_t S, LAM, DU, UQ, XQ, total;
+    size_t S, LAM, DU, DS, DL, DX, UQ, XQ, total;
 };
 SqpLayout sqp_layout(const ilqr_desc &d) {
     const size_t e = 8, Bp = ((size_t)d.B + TILE - 1) / TILE * TILE;
@@ -676,6 +676,9 @@ SqpLayout sqp_layout(const ilqr_desc &d) {
     l.S = take(Bp * N * NR * e);
     l.LAM = take(Bp * N * NR * e);
     l.DU = take(Bp * T1 * m * e);
+    l.DS = take(Bp * N * NR * e);
+    l.DL = take(Bp * N * NR * e);
+    l.DX = take(Bp * N * n * e);
     l.UQ = take(Bp * T1 * m * e);
     l.XQ = take(Bp * N * n * e);
     l.total = off;
@@ -710,6 +713,9 @@ int sqp_args(const ilqr_handle *h, const ilqr_sqp_opts *o, void *work, const voi
     a.S = w + l.S;
     a.LAM = w + l.LAM;
     a.DU = w + l.DU;
+    a.DS = w + l.DS;
+    a.DL = w + l.DL;
+    a.DX = w + l.DX;
     a.UQ = w + l.UQ;
     a.XQ = w + l.XQ;
     a.U0 = o->init_input_fixed ? u0 : nullptr;

@@ -8,7 +8,7 @@
 //                      in every sweep.  The reference hands the sparse QP to OSQP; here it is
 //                      solved by a primal-dual path-following iteration whose Newton step is an
 //                      LQR problem (all inequality rows act on one time step), solved exactly by
-//                      a Riccati recursion: three sweeps over the horizon per iteration.
+//                      a Riccati recursion: two sweeps over the horizon per iteration.
 //                      Jacobian entries a model declares structurally zero or one are skipped at
 //                      compile time (adding an exact zero changes no bit).
 //   sqp_search_kernel  sqp.py:149-171   the step-halving search on the simulated cost, all step
@@ -24,6 +24,7 @@ constexpr int ILQR_STATUS_QP_FAILED_ = 8;
 struct SqpArgs {
     void *S, *LAM;     // slacks and multipliers, rows = N * NR
     void *DU;          // Newton direction of the inputs, rows = (N-1) * NU
+    void *DS, *DL, *DX; // ... of the slacks and multipliers (rows N * NR each) and of the states (rows N * NX)
     void *UQ, *XQ;     // QP iterate: inputs (rows (N-1)*NU) and states (rows N*NX); UQ ends as the solved inputs
     const void *U0;    // fixed first input (rows NU) or null (sqp.py:111-112)
     int32_t *qp_iters; // per problem: iterations of the last QP solve (may be null)
@@ -125,6 +126,9 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
     T *Sp = tile_ptr((T *)a.S, tile, N * NR, ln);
     T *Lp = tile_ptr((T *)a.LAM, tile, N * NR, ln);
     T *DUp = tile_ptr((T *)a.DU, tile, T1 * NU, ln);
+    T *DSp = tile_ptr((T *)a.DS, tile, N * NR, ln);
+    T *DLp = tile_ptr((T *)a.DL, tile, N * NR, ln);
+    T *DXp = tile_ptr((T *)a.DX, tile, N * NX, ln);
     T *UQp = tile_ptr((T *)a.UQ, tile, T1 * NU, ln);
     T *XQp = tile_ptr((T *)a.XQ, tile, N * NX, ln);
     const T *U0p = a.U0 ? tile_ptr((const T *)a.U0, tile, NU, ln) : nullptr;
@@ -146,10 +150,11 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
     // the memory latency of a step hides behind the arithmetic of its predecessor; with one wave per
     // SIMD at these batch sizes nothing else would hide it.
     struct Step {
-        T xb[NX], ub[NU], xq[NX], uq[NU], xr[NX], cx, cy, rad, s[NR], lam[NR], K[NU][NX], k[NU], du[NU];
+        T xb[NX], ub[NU], xq[NX], uq[NU], xr[NX], cx, cy, rad, s[NR], lam[NR], K[NU][NX], k[NU], du[NU], ds[NR], dl[NR], dx[NX];
     };
-    // what: 0 = backward sweep, 1 = forward sweep that needs the gains, 2 = forward sweep that needs the direction
-    auto fetch = [&](int i, int what, Step &st) {
+    // what: 0 = backward sweep (with_step: it also applies the step the last forward sweep found, so it
+    // needs that step), 1 = forward sweep (needs the gains)
+    auto fetch = [&](int i, int what, bool with_step, Step &st) {
         load_x(Xb, i, st.xb);
         load_x(XQp, i, st.xq);
         if (what == 0) load_x(Rt, i, st.xr);
@@ -173,7 +178,15 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
 #pragma unroll
                     for (int q = 0; q < NX; ++q) st.K[r][q] = Kp[(size_t)((i * NU + r) * NX + q) * TILE];
             }
-            if (what == 2) load_u(DUp, i, st.du);
+            if (with_step) load_u(DUp, i, st.du);
+        }
+        if (with_step) {
+            load_x(DXp, i, st.dx);
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                st.ds[j] = DSp[(size_t)(i * NR + j) * TILE];
+                st.dl[j] = DLp[(size_t)(i * NR + j) * TILE];
+            }
         }
     };
 
@@ -243,12 +256,40 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
         mu = nlive > 0 ? mu / (T)nlive : T(0);
     }
 
-    bool done = !active, failed = false;
+    // Per iteration two sweeps: the backward sweep first applies the step found by the previous
+    // forward sweep (an elementwise update, so it can run in the backward order) and then does the
+    // Riccati recursion of the next Newton step on the updated point; the forward sweep finds the
+    // direction and the step lengths and, from four sums, the complementarity the point will have
+    // once the step is applied.  A last sweep applies the step of the final iteration.
+    bool done = !active, failed = false, pending = false;
+    T alpha = T(0), alphad = T(0);
     int it = 0;
+    auto apply = [&](int i, const Step &st, T (&sv)[NR], T (&lv)[NR], T (&xq)[NX], T (&uq)[NU]) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            sv[j] = st.s[j] + alpha * st.ds[j];
+            lv[j] = st.lam[j] + alphad * st.dl[j];
+            Sp[(size_t)(i * NR + j) * TILE] = sv[j];
+            Lp[(size_t)(i * NR + j) * TILE] = lv[j];
+        }
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            xq[q] = st.xq[q] + alpha * st.dx[q];
+            XQp[(size_t)(i * NX + q) * TILE] = xq[q];
+        }
+        if (i < T1) {
+#pragma unroll
+            for (int q = 0; q < NU; ++q) {
+                uq[q] = st.uq[q] + alpha * st.du[q];
+                UQp[(size_t)(i * NU + q) * TILE] = uq[q];
+            }
+        }
+    };
     for (; it < a.qp_max_iter; ++it) {
         if (__ballot(!done) == 0ull) break;
-        // ---- backward sweep: Riccati recursion of the Newton step
+        // ---- backward sweep: pending step applied, then the Riccati recursion of the Newton step
         {
+            const bool any_pending = __ballot(pending) != 0ull;
             T Pm[NX][NX], pv[NX], xbn[NX];
 #pragma unroll
             for (int r = 0; r < NX; ++r) {
@@ -259,15 +300,24 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
             }
             bool bad = false;
             Step nxt;
-            fetch(T1, 0, nxt);
+            fetch(T1, 0, any_pending, nxt);
             for (int i = T1; i >= 0; --i) {
                 const Step st = nxt;
-                if (i > 0) fetch(i - 1, 0, nxt);
+                if (i > 0) fetch(i - 1, 0, any_pending, nxt);
                 const T(&xb)[NX] = st.xb;
                 const T(&ub)[NU] = st.ub;
-                const T(&xq)[NX] = st.xq;
-                const T(&uq)[NU] = st.uq;
                 const T(&xr)[NX] = st.xr;
+                T xq[NX], uq[NU], sv[NR], lv[NR];
+#pragma unroll
+                for (int q = 0; q < NX; ++q) xq[q] = st.xq[q];
+#pragma unroll
+                for (int q = 0; q < NU; ++q) uq[q] = st.uq[q];
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    sv[j] = st.s[j];
+                    lv[j] = st.lam[j];
+                }
+                if (pending) apply(i, st, sv, lv, xq, uq);
                 Rows rows;
                 rows.setup(p, i, T1, xb, st.cx, st.cy, st.rad, fixed0);
                 const T *W = i == T1 ? p.Qf : p.Q;
@@ -295,7 +345,7 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
                     if (!rows.live[j]) continue;
-                    const T s = st.s[j], lam = st.lam[j];
+                    const T s = sv[j], lam = lv[j];
                     const T rp = rows.value(j, xq, uq) + s - rows.bnd[j];
                     const T rc = s * lam - sigma * mu;
                     const T coef = lam + (lam * rp - rc) / s;
@@ -429,35 +479,28 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                 for (int q = 0; q < NX; ++q) xbn[q] = xb[q];
             }
             failed = failed || bad;
+            pending = false;
         }
-        // ---- forward sweeps: 0 = direction and step length, 1 = apply and measure
-        T amax = T(1), dmax = T(1), alpha = T(0), alphad = T(0), gap = T(0), rpmax = T(0), dumax = T(0);
-        for (int pass = 0; pass < 2; ++pass) {
-            T dx[NX], x[NX];
+        // ---- forward sweep: direction, step lengths, and what the step will leave behind
+        T amax = T(1), dmax = T(1), rpabs = T(0), dumax = T(0);
+        T g0 = T(0), g1 = T(0), g2 = T(0), g3 = T(0); // sums of s lam, ds lam, s dl, ds dl over the live rows
+        {
+            T dx[NX];
             Step nxt;
-            fetch(0, pass + 1, nxt);
+            fetch(0, 1, false, nxt);
 #pragma unroll
-            for (int q = 0; q < NX; ++q) {
-                dx[q] = T(0);
-                x[q] = nxt.xb[q];
-            }
-            if (pass == 1) {
-                // separate step lengths: alpha for inputs, states and slacks, alphad for the multipliers
-                const T am = T(0.995) * amax, dm = T(0.995) * dmax;
-                alpha = am < T(1) ? am : T(1);
-                alphad = dm < T(1) ? dm : T(1);
-            }
+            for (int q = 0; q < NX; ++q) dx[q] = T(0);
             for (int i = 0; i < N; ++i) {
                 const Step st = nxt;
-                if (i < T1) fetch(i + 1, pass + 1, nxt);
+                if (i < T1) fetch(i + 1, 1, false, nxt);
                 const T(&xb)[NX] = st.xb;
                 const T(&ub)[NU] = st.ub;
                 const T(&xq)[NX] = st.xq;
                 const T(&uq)[NU] = st.uq;
                 T du[NU];
 #pragma unroll
-                for (int q = 0; q < NU; ++q) du[q] = st.du[q];
-                if (i < T1 && pass == 0) {
+                for (int q = 0; q < NU; ++q) du[q] = T(0);
+                if (i < T1) {
 #pragma unroll
                     for (int r = 0; r < NU; ++r) {
                         T s = st.k[r];
@@ -469,17 +512,21 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                         dumax = m > dumax ? m : dumax;
                     }
                 }
+                if (!done) {
+#pragma unroll
+                    for (int q = 0; q < NX; ++q) DXp[(size_t)(i * NX + q) * TILE] = dx[q];
+                }
                 Rows rows;
                 rows.setup(p, i, T1, xb, st.cx, st.cy, st.rad, fixed0);
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
-                    if (!rows.live[j]) continue;
-                    const T s = st.s[j], lam = st.lam[j];
-                    const T rp = rows.value(j, xq, uq) + s - rows.bnd[j];
-                    const T rc = s * lam - sigma * mu;
-                    const T ds = -rp - rows.along(j, dx, du);
-                    const T dl = (-rc - lam * ds) / s;
-                    if (pass == 0) {
+                    T ds = T(0), dl = T(0);
+                    if (rows.live[j]) {
+                        const T s = st.s[j], lam = st.lam[j];
+                        const T rp = rows.value(j, xq, uq) + s - rows.bnd[j];
+                        const T rc = s * lam - sigma * mu;
+                        ds = -rp - rows.along(j, dx, du);
+                        dl = (-rc - lam * ds) / s;
                         if (ds < T(0)) {
                             const T lim = -s / ds;
                             amax = lim < amax ? lim : amax;
@@ -488,58 +535,47 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                             const T lim = -lam / dl;
                             dmax = lim < dmax ? lim : dmax;
                         }
-                    } else {
-                        const T sn = s + alpha * ds, ln2 = lam + alphad * dl;
-                        gap += sn * ln2;
-                        const T r1 = fabs_(rp) * (T(1) - alpha);
-                        rpmax = r1 > rpmax ? r1 : rpmax;
-                        if (!done) {
-                            Sp[(size_t)(i * NR + j) * TILE] = sn;
-                            Lp[(size_t)(i * NR + j) * TILE] = ln2;
-                        }
+                        g0 += s * lam;
+                        g1 += ds * lam;
+                        g2 += s * dl;
+                        g3 += ds * dl;
+                        const T r1 = fabs_(rp);
+                        rpabs = r1 > rpabs ? r1 : rpabs;
                     }
-                }
-                if (pass == 1 && !done) {
-#pragma unroll
-                    for (int q = 0; q < NX; ++q) XQp[(size_t)(i * NX + q) * TILE] = x[q];
+                    if (!done) {
+                        DSp[(size_t)(i * NR + j) * TILE] = ds;
+                        DLp[(size_t)(i * NR + j) * TILE] = dl;
+                    }
                 }
                 if (i < T1) {
                     T A[NX][NX], Bm[NX][NU], c[NX];
                     sqp_linearise<T, M>(p, i, xb, ub, nxt.xb, A, Bm, c);
-                    T un[NU], dxn[NX], xn[NX];
-#pragma unroll
-                    for (int q = 0; q < NU; ++q) un[q] = uq[q] + alpha * du[q];
+                    T dxn[NX];
 #pragma unroll
                     for (int r = 0; r < NX; ++r) {
-                        T s = T(0), t = c[r];
+                        T s = T(0);
 #pragma unroll
                         for (int q = 0; q < NX; ++q)
-                            if (M::fx_nz(r, q)) {
-                                s += M::fx_one(r, q) ? dx[q] : A[r][q] * dx[q];
-                                t += M::fx_one(r, q) ? x[q] : A[r][q] * x[q];
-                            }
+                            if (M::fx_nz(r, q)) s += M::fx_one(r, q) ? dx[q] : A[r][q] * dx[q];
 #pragma unroll
                         for (int q = 0; q < NU; ++q)
-                            if (M::fu_nz(r, q)) {
-                                s += Bm[r][q] * du[q];
-                                t += Bm[r][q] * un[q];
-                            }
+                            if (M::fu_nz(r, q)) s += Bm[r][q] * du[q];
                         dxn[r] = s;
-                        xn[r] = t;
-                    }
-                    if (pass == 1 && !done) {
-#pragma unroll
-                        for (int q = 0; q < NU; ++q) UQp[(size_t)(i * NU + q) * TILE] = un[q];
                     }
 #pragma unroll
-                    for (int q = 0; q < NX; ++q) {
-                        dx[q] = dxn[q];
-                        x[q] = xn[q];
-                    }
+                    for (int q = 0; q < NX; ++q) dx[q] = dxn[q];
                 }
             }
         }
         if (!done) {
+            // separate step lengths: alpha for inputs, states and slacks, alphad for the multipliers
+            const T am = T(0.995) * amax, dm = T(0.995) * dmax;
+            alpha = am < T(1) ? am : T(1);
+            alphad = dm < T(1) ? dm : T(1);
+            pending = true;
+            // complementarity and row residual of the point once the step is applied
+            const T gap = g0 + alpha * g1 + alphad * g2 + (alpha * alphad) * g3;
+            const T rpmax = rpabs * (T(1) - alpha);
             mu = nlive > 0 ? gap / (T)nlive : T(0);
             const bool finite = fabs_(mu) < inf_<T>() && fabs_(dumax) < inf_<T>();
             // a step length that collapses means the rows cannot all be met (the multipliers of an
@@ -551,6 +587,15 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                 done = true;
             }
             if (done && a.qp_iters) a.qp_iters[b] = it + 1;
+        }
+    }
+    // ---- the step of the last iteration
+    if (__ballot(pending) != 0ull) {
+        for (int i = 0; i < N; ++i) {
+            Step st;
+            fetch(i, 0, true, st);
+            T xq[NX], uq[NU], sv[NR], lv[NR];
+            if (pending) apply(i, st, sv, lv, xq, uq);
         }
     }
     if (active && (!done || failed)) {

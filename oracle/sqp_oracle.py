@@ -23,7 +23,7 @@ and the QP itself is solved to 1e-10 in two independent ways:
                         predictor-corrector interior-point iteration with dense factorisations;
     solve_qp_riccati()  the statement of the GPU kernel's method in numpy: a primal-dual
                         path-following iteration in (inputs, slacks, multipliers) whose Newton
-                        step is an LQR problem solved by a Riccati recursion, three sweeps over
+                        step is an LQR problem solved by a Riccati recursion, two sweeps over
                         the horizon per iteration.
 """
 import numpy as np
@@ -229,7 +229,8 @@ def solve_qp_riccati(system, target, x0, A, B, c, G, lo, hi, umin, umax, u_start
                       g~ = H z + g + R' (lam + (lam rp - rc) / s),  rp = R z + s - h,  rc = s lam - sigma mu;
       forward sweep 1: dz by rollout, ds = -rp - R dz, dlam = (-rc - lam ds) / s, largest steps that keep
                       s and lam positive;
-      forward sweep 2: the step is applied and mu, |rp| of the new point are measured.
+      then the step is applied elementwise; mu and |rp| of the new point follow from sums taken
+                      in the forward sweep.
     Rows of a step, in this order: bubble upper, speed lower, speed upper (steps 1..N-1), then per
     input lower, upper (steps 0..N-2).  Infinite bounds give rows that are skipped."""
     N, n, m = target.shape[0], system.state_size, system.control_size
@@ -345,13 +346,16 @@ def solve_qp_riccati(system, target, x0, A, B, c, G, lo, hi, umin, umax, u_start
         # separate step lengths: `a` for inputs, states and slacks, `ad` for the multipliers
         a = min(1.0, 0.995 * a_max)
         ad = min(1.0, 0.995 * d_max)
-        # forward sweep 2: apply, measure
+        # the step is applied elementwise (the kernel does it at the start of its next backward sweep);
+        # complementarity and row residual of the new point follow from four sums
+        g0 = g1 = g2 = g3 = 0.0
+        rp_abs = 0.0
         dx = np.zeros(n)
-        x = np.array(x0, float)
-        gap = 0.0
-        rp_max = 0.0
+        dxs = np.zeros((N, n))
+        dss = np.zeros((N, NR))
+        dls = np.zeros((N, NR))
         for i in range(N):
-            un = u[i] + a * du[i] if i < T else None
+            dxs[i] = dx
             for j, (val, bnd, gx, gu) in enumerate(rows_of(i, xs[i], u[i] if i < T else None)):
                 if not live[i, j]:
                     continue
@@ -359,15 +363,20 @@ def solve_qp_riccati(system, target, x0, A, B, c, G, lo, hi, umin, umax, u_start
                 rc = s[i, j] * lam[i, j] - sigma * mu
                 ds = -rp - (gx @ dx if gx is not None else gu @ du[i])
                 dl = (-rc - lam[i, j] * ds) / s[i, j]
-                s[i, j] += a * ds
-                lam[i, j] += ad * dl
-                gap += s[i, j] * lam[i, j]
-                rp_max = max(rp_max, abs(rp) * (1.0 - a))
-            xs[i] = x
+                dss[i, j], dls[i, j] = ds, dl
+                g0 += s[i, j] * lam[i, j]
+                g1 += ds * lam[i, j]
+                g2 += s[i, j] * dl
+                g3 += ds * dl
+                rp_abs = max(rp_abs, abs(rp))
             if i < T:
                 dx = A[i] @ dx + B[i] @ du[i]
-                x = A[i] @ x + B[i] @ un + c[i]
-                u[i] = un
+        s = s + a * dss
+        lam = lam + ad * dls
+        xs = xs + a * dxs
+        u = u + a * du
+        gap = g0 + a * g1 + ad * g2 + (a * ad) * g3
+        rp_max = rp_abs * (1.0 - a)
         mu = gap / nlive
         step = np.abs(du).max() * a
         if info is not None:
