@@ -150,11 +150,10 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
     // the memory latency of a step hides behind the arithmetic of its predecessor; with one wave per
     // SIMD at these batch sizes nothing else would hide it.
     struct Step {
-        T xb[NX], ub[NU], xq[NX], uq[NU], xr[NX], cx, cy, rad, s[NR], lam[NR], K[NU][NX], k[NU], du[NU], ds[NR], dl[NR], dx[NX];
+        T xb[NX], ub[NU], xq[NX], uq[NU], xr[NX], cx, cy, rad, s[NR], lam[NR], K[NU][NX], k[NU];
     };
-    // what: 0 = backward sweep (with_step: it also applies the step the last forward sweep found, so it
-    // needs that step), 1 = forward sweep (needs the gains)
-    auto fetch = [&](int i, int what, bool with_step, Step &st) {
+    // what: 0 = backward sweep, 1 = forward sweep (needs the gains)
+    auto fetch = [&](int i, int what, Step &st) {
         load_x(Xb, i, st.xb);
         load_x(XQp, i, st.xq);
         if (what == 0) load_x(Rt, i, st.xr);
@@ -167,7 +166,7 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
             st.lam[j] = Lp[(size_t)(i * NR + j) * TILE];
         }
 #pragma unroll
-        for (int q = 0; q < NU; ++q) st.ub[q] = st.uq[q] = st.k[q] = st.du[q] = T(0);
+        for (int q = 0; q < NU; ++q) st.ub[q] = st.uq[q] = st.k[q] = T(0);
         if (i < T1) {
             load_u(Ub, i, st.ub);
             load_u(UQp, i, st.uq);
@@ -178,15 +177,23 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
 #pragma unroll
                     for (int q = 0; q < NX; ++q) st.K[r][q] = Kp[(size_t)((i * NU + r) * NX + q) * TILE];
             }
-            if (with_step) load_u(DUp, i, st.du);
         }
-        if (with_step) {
-            load_x(DXp, i, st.dx);
+    };
+    // the step the last forward sweep found, for one time step.  Not fetched ahead (that would
+    // cost its registers for a whole step): a sweep issues these loads at the top of a step and does
+    // work that does not need them first
+    struct Delta {
+        T ds[NR], dl[NR], dx[NX], du[NU];
+    };
+    auto fetch_delta = [&](int i, Delta &dv) {
+        load_x(DXp, i, dv.dx);
 #pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                st.ds[j] = DSp[(size_t)(i * NR + j) * TILE];
-                st.dl[j] = DLp[(size_t)(i * NR + j) * TILE];
-            }
+        for (int q = 0; q < NU; ++q) dv.du[q] = T(0);
+        if (i < T1) load_u(DUp, i, dv.du);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            dv.ds[j] = DSp[(size_t)(i * NR + j) * TILE];
+            dv.dl[j] = DLp[(size_t)(i * NR + j) * TILE];
         }
     };
 
@@ -264,23 +271,23 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
     bool done = !active, failed = false, pending = false;
     T alpha = T(0), alphad = T(0);
     int it = 0;
-    auto apply = [&](int i, const Step &st, T (&sv)[NR], T (&lv)[NR], T (&xq)[NX], T (&uq)[NU]) {
+    auto apply = [&](int i, const Step &st, const Delta &dv, T (&sv)[NR], T (&lv)[NR], T (&xq)[NX], T (&uq)[NU]) {
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-            sv[j] = st.s[j] + alpha * st.ds[j];
-            lv[j] = st.lam[j] + alphad * st.dl[j];
+            sv[j] = st.s[j] + alpha * dv.ds[j];
+            lv[j] = st.lam[j] + alphad * dv.dl[j];
             Sp[(size_t)(i * NR + j) * TILE] = sv[j];
             Lp[(size_t)(i * NR + j) * TILE] = lv[j];
         }
 #pragma unroll
         for (int q = 0; q < NX; ++q) {
-            xq[q] = st.xq[q] + alpha * st.dx[q];
+            xq[q] = st.xq[q] + alpha * dv.dx[q];
             XQp[(size_t)(i * NX + q) * TILE] = xq[q];
         }
         if (i < T1) {
 #pragma unroll
             for (int q = 0; q < NU; ++q) {
-                uq[q] = st.uq[q] + alpha * st.du[q];
+                uq[q] = st.uq[q] + alpha * dv.du[q];
                 UQp[(size_t)(i * NU + q) * TILE] = uq[q];
             }
         }
@@ -300,10 +307,12 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
             }
             bool bad = false;
             Step nxt;
-            fetch(T1, 0, any_pending, nxt);
+            fetch(T1, 0, nxt);
             for (int i = T1; i >= 0; --i) {
                 const Step st = nxt;
-                if (i > 0) fetch(i - 1, 0, any_pending, nxt);
+                if (i > 0) fetch(i - 1, 0, nxt);
+                Delta dv;
+                if (any_pending) fetch_delta(i, dv);
                 const T(&xb)[NX] = st.xb;
                 const T(&ub)[NU] = st.ub;
                 const T(&xr)[NX] = st.xr;
@@ -317,7 +326,11 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                     sv[j] = st.s[j];
                     lv[j] = st.lam[j];
                 }
-                if (pending) apply(i, st, sv, lv, xq, uq);
+                // the linearisation needs nothing of the pending step: its arithmetic covers the latency of
+                // the loads just issued
+                T A[NX][NX], Bm[NX][NU], c[NX];
+                if (i < T1) sqp_linearise<T, M>(p, i, xb, ub, xbn, A, Bm, c);
+                if (pending) apply(i, st, dv, sv, lv, xq, uq);
                 Rows rows;
                 rows.setup(p, i, T1, xb, st.cx, st.cy, st.rad, fixed0);
                 const T *W = i == T1 ? p.Qf : p.Q;
@@ -374,8 +387,6 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                         for (int q = 0; q < NX; ++q) Pm[r][q] = Hx[r][q];
                     }
                 } else {
-                    T A[NX][NX], Bm[NX][NU], c[NX];
-                    sqp_linearise<T, M>(p, i, xb, ub, xbn, A, Bm, c);
                     // PA = P A, PB = P B
                     T PA[NX][NX], PB[NX][NU];
 #pragma unroll
@@ -487,12 +498,12 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
         {
             T dx[NX];
             Step nxt;
-            fetch(0, 1, false, nxt);
+            fetch(0, 1, nxt);
 #pragma unroll
             for (int q = 0; q < NX; ++q) dx[q] = T(0);
             for (int i = 0; i < N; ++i) {
                 const Step st = nxt;
-                if (i < T1) fetch(i + 1, 1, false, nxt);
+                if (i < T1) fetch(i + 1, 1, nxt);
                 const T(&xb)[NX] = st.xb;
                 const T(&ub)[NU] = st.ub;
                 const T(&xq)[NX] = st.xq;
@@ -593,9 +604,11 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
     if (__ballot(pending) != 0ull) {
         for (int i = 0; i < N; ++i) {
             Step st;
-            fetch(i, 0, true, st);
+            Delta dv;
+            fetch(i, 0, st);
+            fetch_delta(i, dv);
             T xq[NX], uq[NU], sv[NR], lv[NR];
-            if (pending) apply(i, st, sv, lv, xq, uq);
+            if (pending) apply(i, st, dv, sv, lv, xq, uq);
         }
     }
     if (active && (!done || failed)) {
