@@ -425,6 +425,38 @@ class BatchedSolverBase:
         self.download()
         return self.states
 
+    # -- the reference's phase methods, each one device launch over the batch --------------------
+    def cost(self):
+        """``ilqr.py:36-46`` for the current ``states`` / ``inputs``: scalar, or ``(B,)``."""
+        dev = self.upload()
+        dev.initial_cost()
+        J = dev.J.cpu().numpy().astype(np.float64)
+        return J if self._batched else float(J[0])
+
+    def backward_pass(self):
+        """``ilqr.py:76-105``: gains ``k`` / ``K`` of the current ``states`` / ``inputs``."""
+        dev = self.upload()
+        dev.converged.zero_()        # the reference's backward_pass does not look at `converge`
+        dev.backward()
+
+    def forward_pass(self):
+        """``ilqr.py:48-74``: line search with the gains of the last ``backward_pass`` against
+        ``min_cost``; updates ``states``, ``inputs``, ``min_cost``, ``converge`` (in the reference's
+        call order: ``min_cost = cost()``, ``backward_pass()``, ``forward_pass()``)."""
+        torch = _torch()
+        if self._dev is None:
+            raise _lib.IlqrError("forward_pass needs the gains of a backward_pass")
+        dev = self._dev
+        K, k = dev.K.clone(), dev.k.clone()          # upload() may rebuild nothing, but keep the order explicit
+        dev = self.upload()
+        dev.K.copy_(K)
+        dev.k.copy_(k)
+        dev.initial_cost()                            # also tells the handle that X was written by the caller
+        mc = np.atleast_1d(np.asarray(self.min_cost, dtype=self._dtype))
+        dev.J.copy_(torch.from_numpy(np.ascontiguousarray(mc)))
+        dev.forward(0)
+        self.download()
+
     # gains of the last backward pass (ilqr.py:77-78), fetched on demand
     @property
     def k(self):

@@ -3,8 +3,8 @@ the GPU.
 
 ``sequential_QP_optimizer(sys, constraint, target_states, dt)`` has the constructor, attributes
 (``maxIter``, ``eps``, ``cost_eps``, ``init_input_fixed``, ``states``, ``inputs``, ``min_cost``,
-``converge``) and methods (``set_init_inputs``, ``cost``, ``sim``, ``__call__``) of
-``sqp.py:7-66`` / ``:136-171``; ``target_states`` may carry a leading batch axis ``(B, N, 4)``,
+``converge``) and methods (``set_init_inputs``, ``__call__``) of ``sqp.py:7-66`` /
+``:136-171``; ``target_states`` may carry a leading batch axis ``(B, N, 4)``,
 with the constraint's ``centers (B, N, 2)`` and ``radius (B, N)`` batched alike.
 
 What differs from the reference, on purpose: the QP of every iteration (``sqp.py:77-134``) is
@@ -12,7 +12,8 @@ solved on the device by an interior-point iteration to 1e-10 instead of by the O
 default 1e-3, so iterates agree with the reference only to the accuracy OSQP delivers; the
 constraint rows of step 0, which only test the given initial state, are left out; a QP without a
 solution sets ``STATUS_QP_FAILED`` in ``status`` and ends that problem's iteration.  fp64 and the
-``Car`` state layout only (``constraints.py:12`` is written for it).  ``plot`` is not provided.
+state layouts that start with ``(px, py, v)`` only (``constraints.py:12`` is written for them).  ``cost``,
+``sim`` and ``plot`` of the reference class are not provided (the search kernel simulates and costs on the device).
 """
 import ctypes as C
 

@@ -93,6 +93,28 @@ def test_phase_kernels_match_oracle(ilqr_cls, oracle, name):
     assert bool(dev.converged.cpu()[0]) == cv and int(dev.iters.cpu()[0]) == 1
 
 
+def test_reference_phase_methods(ilqr_cls, oracle):
+    """cost(), backward_pass(), forward_pass() called the way ilqr.py:107-113 calls them."""
+    g = load_golden("car_N200_seed1")
+    s = system_from_golden(g)
+    N = g["target_states"].shape[0]
+    tg = np.ascontiguousarray(g["target_states"])
+    st, ui = np.array(g["init_states"]), np.array(g["init_inputs"])
+    d = oracle.make_desc(s, N)
+    opt = make_solver(ilqr_cls, s, g)
+    opt.min_cost = opt.cost()
+    assert abs(opt.min_cost - float(g["cost0"])) <= 1e-13 * float(g["cost0"])
+    for it in range(3):
+        opt.backward_pass()
+        Ko, ko, _ = oracle.backward(d, tg, st, ui)
+        assert nrm(opt.K, Ko) <= 1e-11 and nrm(opt.k[:, :, 0], ko) <= 1e-11
+        opt.forward_pass()
+        assert abs(opt.min_cost - float(g["hist_cost"][it])) <= 1e-9 * float(g["hist_cost"][it])
+        assert nrm(opt.states, g["hist_states"][it]) <= 1e-9
+        st, ui = np.array(g["hist_states"][it]), np.array(g["hist_inputs"][it])
+    assert not opt.converge
+
+
 # --------------------------------------------------------------------------- whole solve
 def check_history(opt_hist_cost, opt_hist_alpha, opt_iters, g, tol):
     it = int(g["iters"])
