@@ -223,8 +223,9 @@ int ilqr_model_probe(int32_t model, int32_t dtype, double dt, int32_t t, const v
  * primal-dual interior-point iteration whose Newton step is a Riccati recursion (to qp_tol, far
  * below OSQP's default 1e-3).
  *
- * Needs a handle created for ILQR_MODEL_CAR, ILQR_F64 with ILQR_CONSTR_BARRIER set in
- * constraint_mode (so that centers and radius are bound; barrier_mu / barrier_delta are not used)
+ * Needs a handle created for ILQR_MODEL_CAR (or for a model loaded with ilqr_load_model whose
+ * library was built with the (px, py, v) state layout declared), ILQR_F64, with ILQR_CONSTR_BARRIER
+ * set in constraint_mode (so that centers and radius are bound; barrier_mu / barrier_delta are not used)
  * and vel_bounds filled; control_limited selects whether the QP bounds the inputs (sqp.py:38-42).
  * Before the call: X = target_states (sqp.py:138; its first row is x0, sqp.py:37), U = initial
  * inputs.  After it: X, U, J (min_cost), converged, iters, alpha_idx, status, history as for
