@@ -122,3 +122,27 @@ def test_sqp_entry_points_refuse_what_they_cannot_do():
     h = _handle(_lib.CONSTR_BARRIER, dtype=_lib.F32)                                 # fp64 only
     assert lib.ilqr_sqp_begin(h, None) == -2
     lib.ilqr_destroy(h)
+
+
+def test_python_class_surface_and_refusal_without_gpu():
+    """Constructor, attributes and defaults of sqp.py:17-42 / :63-65; no CPU fallback."""
+    import torch
+    from ilqr_amd.sqp import sequential_QP_optimizer
+    tg, ui, c, r, vb = problems.demo_sqp(30, 0)
+    car = sqp_car(30)
+    con = BubbleConstraint(30)
+    con.setup(c, r, vb)
+    o = sequential_QP_optimizer(car, con, tg, 0.2)
+    assert (o.horizon, o.n_states, o.m_inputs, o.maxIter, o.eps, o.cost_eps, o.init_input_fixed, o.converge) == \
+        (30, 4, 2, 20, 1e-2, 1e-6, False, False)
+    assert o.states.shape == (30, 4) and o.inputs.shape == (29, 2) and o.Qf is car.Q_f
+    assert np.array_equal(o.x0, tg[0]) and list(o.umin) == [-1.0, -0.3] and list(o.umax) == [1.0, 0.3]
+    o.set_init_inputs(ui)
+    assert o.inputs is ui and np.array_equal(o.u0, ui[0])
+    free = sequential_QP_optimizer(sqp_car(30, limits=None), con, tg, 0.2)
+    assert np.all(np.isinf(free.umin)) and np.all(np.isinf(free.umax))           # sqp.py:38-39
+    ob = sequential_QP_optimizer(car, con, np.stack([tg, tg, tg]), 0.2)
+    assert ob.states.shape == (3, 30, 4) and ob.x0.shape == (3, 4)
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.IlqrError):
+            o()
