@@ -149,3 +149,27 @@ def test_numpy_only_model_in_the_sequential_qp():
     ref = so.sqp_solve(car, con, tg, ui, qp="riccati")
     _check_against_oracle(opt.cost_history, opt.alpha_history, opt.iterations, ref)
     assert opt.status == 0 and np.abs(opt.states - ref["states"]).max() <= 1e-7
+
+
+@pytest.mark.parametrize("seed,rad,vb,lim", CASES[1:])
+@pytest.mark.parametrize("fixed", [False, True])
+def test_whole_solves_with_active_rows(seed, rad, vb, lim, fixed):
+    """Whole solves in which speed rows, input bounds and bubble rows are active in the QPs, with
+    and without the fixed first input (sqp.py:36, :111-112)."""
+    from oracle import sqp_oracle as so
+    from ilqr_amd import problems
+    N = 60
+    tg, ui, c, r, _ = problems.demo_sqp(N, seed, radius=rad)
+    car = sqp_car(N, lim)
+    opt, con = _solver(car, c, r, vb, tg, ui)
+    opt.init_input_fixed = fixed
+    opt.maxIter = 6
+    opt()
+    ref = so.sqp_solve(car, con, tg, ui, max_iter=6, init_input_fixed=fixed, qp="riccati")
+    if opt.status == 0:
+        n = _check_against_oracle(opt.cost_history, opt.alpha_history, opt.iterations, ref, tol=1e-8)
+        assert n >= 1
+        if fixed and opt.alpha_history[0] == 0:
+            assert np.allclose(opt.inputs[0], ui[0], rtol=0, atol=1e-12) or opt.iterations > 1
+    else:
+        assert opt.status == 8 and opt.converge
