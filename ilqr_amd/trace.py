@@ -16,13 +16,19 @@ The emitted code performs the recorded operations in the recorded order with
 no fused multiply-adds (the library is compiled with ``-ffp-contract=off``), i.e.
 the same roundings as numpy up to the last bit of the transcendental functions.
 
+Two other common idioms are supported by letting them through while the methods
+are being recorded (``_recording_numpy``): arrays made with ``np.zeros`` /
+``np.eye`` / ... and filled by item assignment, and ``np.asarray(x, dtype=float)``.
+
 What cannot be traced (the caller then gets a ``TraceError`` that says so and
 can write the snippets by hand, ``systems.DeviceSystem``): data-dependent
 branches or comparisons, conversion of state values to Python floats/ints
-(``float(x[0])``, ``np.asarray(x, dtype=float)``), and functions outside the
-table below.
+(``float(x[0])``), numpy functions imported by name (``from numpy import
+zeros``) in the idioms above, and functions outside the table below.
 """
+import contextlib
 import math
+import threading
 
 import numpy as np
 
@@ -126,7 +132,7 @@ class Sym:
 
     def _refuse(self, *_):
         raise TraceError("the model compares or converts a state/control value (data-dependent branch, float(), "
-                         "int(), dtype=float): it is not straight-line arithmetic and cannot be traced; "
+                         "int()): it is not straight-line arithmetic and cannot be traced; "
                          "derive it from systems.DeviceSystem and write the device snippets by hand")
 
     __lt__ = __le__ = __gt__ = __ge__ = __bool__ = __float__ = __int__ = __index__ = _refuse
@@ -222,6 +228,62 @@ def _flat(out, count, what):
     return list(a)
 
 
+_FLOAT_DTYPES = (float, np.float64, np.float32, "float", "float64", "float32", "d", "f8")
+_ALLOCATORS = ("zeros", "ones", "empty", "full", "eye", "identity", "zeros_like", "ones_like", "empty_like", "full_like")
+_CONVERTERS = ("asarray", "array", "ascontiguousarray", "asanyarray")
+_patch_lock = threading.Lock()
+
+
+def _holds_sym(obj):
+    if isinstance(obj, Sym):
+        return True
+    if isinstance(obj, np.ndarray):
+        return obj.dtype == object and any(isinstance(v, Sym) for v in obj.reshape(-1))
+    if isinstance(obj, (list, tuple)):
+        return any(_holds_sym(v) for v in obj)
+    return False
+
+
+@contextlib.contextmanager
+def _recording_numpy():
+    """While the methods are being recorded, the two idioms that would otherwise stop a recording
+    scalar at the door are let through: arrays allocated with ``np.zeros`` / ``np.eye`` / ... and
+    filled by item assignment hold objects instead of floats, and ``np.asarray(x, dtype=float)``
+    (and friends) of recording scalars keeps them instead of converting.  Only the attributes of
+    the ``numpy`` module that user code reaches as ``np.<name>`` are replaced, only for the
+    duration of the three calls, under a lock; numpy's own internals do not go through them.  The
+    record is validated against the unmodified methods afterwards."""
+    saved = {}
+
+    def allocator(fn):
+        def wrapped(*a, **k):
+            out = fn(*a, **k)
+            return out.astype(object) if isinstance(out, np.ndarray) and out.dtype.kind in "fiu" else out
+        return wrapped
+
+    def converter(fn):
+        def wrapped(obj, *a, **k):
+            dt = k.get("dtype", a[0] if a else None)
+            if _holds_sym(obj) and (dt is None or dt in _FLOAT_DTYPES or dt is object):
+                k.pop("dtype", None)
+                return fn(obj, *a[1:], dtype=object, **k)
+            return fn(obj, *a, **k)
+        return wrapped
+
+    with _patch_lock:
+        try:
+            for name in _ALLOCATORS:
+                saved[name] = getattr(np, name)
+                setattr(np, name, allocator(saved[name]))
+            for name in _CONVERTERS:
+                saved[name] = getattr(np, name)
+                setattr(np, name, converter(saved[name]))
+            yield
+        finally:
+            for name, fn in saved.items():
+                setattr(np, name, fn)
+
+
 def trace_system(system, check_points=8, seed=0):
     """Record ``model_f``, ``compute_df_dx`` and ``compute_df_du`` of ``system``.
 
@@ -231,9 +293,10 @@ def trace_system(system, check_points=8, seed=0):
     n, m = int(system.state_size), int(system.control_size)
     g = _Graph(n, m)
     try:
-        f = _flat(system.model_f(g.x.copy(), g.u.copy()), n, "model_f")
-        fx = _flat(system.compute_df_dx(g.x.copy(), g.u.copy()), n * n, "compute_df_dx")
-        fu = _flat(system.compute_df_du(g.x.copy(), g.u.copy()), n * m, "compute_df_du")
+        with _recording_numpy():
+            f = _flat(system.model_f(g.x.copy(), g.u.copy()), n, "model_f")
+            fx = _flat(system.compute_df_dx(g.x.copy(), g.u.copy()), n * n, "compute_df_dx")
+            fu = _flat(system.compute_df_du(g.x.copy(), g.u.copy()), n * m, "compute_df_du")
     except TraceError:
         raise
     except Exception as e:  # numpy refuses an operation on the recording objects

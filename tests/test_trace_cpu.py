@@ -93,7 +93,60 @@ class _WrongShape(_Branchy):
         return np.array([[0.0, 0.0], [self.dt, 0.0]])
 
 
-@pytest.mark.parametrize("cls,needle", [(_Branchy, "compares or converts"), (_Coercing, "cannot be traced"),
+class _FloatCall(_Branchy):
+    def model_f(self, x, u):
+        return np.array([x[0] + float(x[1]) * self.dt, x[1] + u[0] * self.dt])
+
+
+class _FillIn(System):
+    """arrays allocated with numpy and filled by item assignment"""
+
+    def __init__(self):
+        super().__init__(3, 1)
+        self.dt = 0.1
+
+    def model_f(self, x, u):
+        xn = np.zeros(3)
+        xn[0] = x[0] + x[1] * self.dt
+        xn[1] = x[1] + np.sin(x[2]) * self.dt
+        xn[2] = x[2] + u[0] * self.dt
+        return xn
+
+    def compute_df_dx(self, x, u):
+        J = np.eye(3)
+        J[0, 1] = self.dt
+        J[1, 2] = np.cos(x[2]) * self.dt
+        return J
+
+    def compute_df_du(self, x, u):
+        J = np.zeros((3, 1))
+        J[2, 0] = self.dt
+        return J
+
+
+def test_allocation_and_coercion_idioms_are_recorded():
+    """np.zeros / np.eye + item assignment and np.asarray(x, dtype=float) do not stop the recorder;
+    numpy itself is untouched afterwards.  The vectorised statements of the shipped models record to
+    the sparsity patterns their hand-written device code declares."""
+    from ilqr_amd import systems
+    t = trace.trace_system(_FillIn())
+    assert t["fx_pattern"].tolist() == [[2, 1, 0], [0, 2, 1], [0, 0, 2]] and t["fu_pattern"].tolist() == [[0], [0], [1]]
+    assert "fx[1][2] =" in t["jac"] and t["step"].count("sincos_<FAST>") == 1
+    t = trace.trace_system(_Coercing())
+    assert "xn[1] =" in t["step"]
+    hand = KinematicBicycle()
+    t = trace.trace_system(hand)                 # np.asarray(x, dtype=float), x[..., i], np.stack, J[..., i, j] = ...
+    assert np.array_equal(t["fx_pattern"], hand.fx_pattern) and np.array_equal(t["fu_pattern"], hand.fu_pattern)
+    car = trace.trace_system(systems.Car())
+    assert car["fx_pattern"].tolist() == [[2, 0, 1, 1], [0, 2, 1, 1], [0, 0, 2, 0], [0, 0, 0, 2]]   # CarModel::fx_nz / fx_one
+    assert car["fu_pattern"].tolist() == [[0, 0], [0, 0], [1, 0], [0, 1]]
+    dub = trace.trace_system(systems.DubinsCar())
+    assert dub["fu_pattern"].tolist() == [[1, 0], [1, 0], [1, 1]]                                      # DubinsModel::fu_nz
+    assert np.zeros(2).dtype == np.float64 and np.eye(2).dtype == np.float64
+    assert np.asarray([1, 2], dtype=float).dtype == np.float64
+
+
+@pytest.mark.parametrize("cls,needle", [(_Branchy, "compares or converts"), (_FloatCall, "compares or converts"),
                                         (_Stateful, "does not compute the same values"),
                                         (_WrongShape, "returned 4 values, expected 2")])
 def test_untraceable_models_are_refused_with_a_reason(cls, needle):
