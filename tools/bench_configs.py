@@ -2,7 +2,7 @@
 """Whole-solve timings of the secondary workloads (the ones bench.py does not quote): one JSON
 line per configuration, inputs resident in HBM, time = ilqr_solve on the device, median of reps.
 
-    python tools/bench_configs.py [--reps 3] [--only car4096,cilqr16384,car65536_f32,ltv_f64,ltv_f32]
+    python tools/bench_configs.py [--reps 3] [--only car4096,cilqr16384,car65536_f32,ltv_f64,ltv_f32,sqp16384,sqp65536]
 """
 import argparse
 import json
@@ -57,9 +57,9 @@ def build(name):
         opt = iterative_LQR(s, p["target_states"], 0.05, dtype=np.float32 if name.endswith("f32") else np.float64)
         opt.inputs, opt.states = p["init_inputs"], p["init_states"]
         return opt, f"LTV n=12 m=4, B={B}, N={N}, maxIter=30, {'fp32' if name.endswith('f32') else 'fp64'}"
-    if name == "sqp16384":
+    if name in ("sqp16384", "sqp65536"):
         from ilqr_amd.sqp import sequential_QP_optimizer
-        B, N = 16384, 80
+        B, N = int(name[3:]), 80
         p = problems.sqp_batch(B, N)
         car = systems.Car()
         car.set_dt(0.2)
