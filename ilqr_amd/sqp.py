@@ -79,7 +79,16 @@ class sequential_QP_optimizer:
         """Device buffers and the start of sqp.py:137-140: states = target_states, inputs as set."""
         torch = _torch()
         c = self.constraint
+        sy = self.system
+        key = (self._B, self.horizon, int(self.maxIter), float(sy.dt), np.asarray(sy.Q).tobytes(), np.asarray(sy.R).tobytes(),
+               np.asarray(sy.Q_f).tobytes(), bool(sy.control_limited),
+               (tuple(sy.control_lower_limit), tuple(sy.control_upper_limit)) if sy.control_limited else None,
+               tuple(float(v) for v in c.vel_bounds))
+        if self._dev is not None and self._dev_key != key:   # the model setup changed since the last call
+            self._dev.close()
+            self._dev = None
         if self._dev is None:
+            self._dev_key = key
             self._dev = DeviceProblem(self.system, self._B, self.horizon, np.float64, self._device, max_iter=self.maxIter,
                                       lm_parameter=0.0, alpha_floor=self.eps, constraint_mode=_lib.CONSTR_BARRIER,
                                       barrier_mu=0.0, barrier_delta=1.0, vel_bounds=tuple(c.vel_bounds),
