@@ -264,7 +264,9 @@ def cpu_baseline(car, p, N, sample):
     el = time.perf_counter() - t0
     return {"value": sample / el, "unit": "solves/s", "cores": cores, "kind": "port",
             "sample": f"first {sample} problems of the same batch, C oracle (scalar fp64 port of ilqr.py), "
-                      f"OpenMP over problems, {el:.1f} s wall, mean {float(r['iters'].mean()):.1f} iterations"}
+                      f"OpenMP over problems, {el:.1f} s wall, mean {float(r['iters'].mean()):.1f} iterations",
+            "note": "the reference itself (numpy ilqr.py) ran the same problems at 1.10 solves/s per core in the build "
+                    "container, 280x slower per core than this port; it cannot travel to the GPU box"}
 
 
 if __name__ == "__main__":
