@@ -100,13 +100,17 @@ def test_auto_choices_and_workspace_of_a_handle():
     assert big - small >= 2 * 65536 * (2 * 200 * 4 + 199 * 2) * 8
     lib.ilqr_destroy(h)
     rc, h = _create(_desc(B=4096, N=200))
-    assert rc == 0 and mapping(h) == (8, 1)          # small batch: more lanes per problem
+    assert rc == 0 and mapping(h) == (16, 1)         # small batch: all step sizes in one stage, a lane each
     assert lib.ilqr_workspace_bytes(h) < 4096 * 200 * 4 * 8   # below the compaction threshold
     for fn in (lib.ilqr_repack, lib.ilqr_unpack, lib.ilqr_initial_cost, lib.ilqr_forward_evaluate):
         assert fn(h, None) == -3
     assert lib.ilqr_forward_evaluate_stage(h, 1, None) == -3
     assert lib.ilqr_shift(h, 1, None, None) == -3
     lib.ilqr_destroy(h)
+    for B, want in ((8192, (8, 2)), (16384, (4, 4)), (32768, (2, 4))):
+        rc, h = _create(_desc(B=B, N=200))
+        assert rc == 0 and mapping(h) == want
+        lib.ilqr_destroy(h)
     rc, h = _create(_desc(alpha_floor=1e-2, B=65536))
     assert rc == 0 and mapping(h) == (1, 8)          # 8 step sizes (cilqr.py:41): a single stage
     lib.ilqr_destroy(h)
