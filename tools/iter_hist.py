@@ -1,5 +1,9 @@
-import sys, time
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+"""Development aid: distribution of executed iterations per problem for two secondary workloads."""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np, torch
 import bench_configs as bc
 for name in ("cilqr16384", "car16384"):
