@@ -105,6 +105,15 @@ def test_batch_matches_oracle_and_does_not_depend_on_sharding():
         con.setup(p["centers"][b], p["radius"][b], p["vel_bounds"])
         ref = so.sqp_solve(car, con, p["target_states"][b], p["init_inputs"][b], qp="riccati")
         _check_against_oracle(opt.cost_history[b], opt.alpha_history[b], opt.iterations[b], ref)
+    # properties that hold for every problem, whatever its size: the returned states are the
+    # simulation of the returned inputs (sqp.py:158), accepted costs only ever fall (sqp.py:160-162),
+    # min_cost is the cost of the returned trajectory (sqp.py:44-54)
+    for b in range(B):
+        assert np.abs(so.sim(car, p["target_states"][b, 0], opt.inputs[b]) - opt.states[b]).max() <= 1e-11
+        h = opt.cost_history[b, :int(opt.iterations[b])]
+        assert np.all(np.diff(h) <= 0)
+        c = so.cost(car, p["target_states"][b], opt.states[b], opt.inputs[b])
+        assert abs(c - opt.min_cost[b]) <= 1e-11 * abs(c)
     # problems whose linearised rows cannot be met are flagged, stop, and keep a valid trajectory
     bad = ~ok
     assert np.all(opt.status[bad] == 8) and np.all(opt.converge[bad]) and np.all(np.isfinite(opt.states))
