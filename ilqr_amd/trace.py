@@ -251,20 +251,24 @@ def _recording_numpy():
     filled by item assignment hold objects instead of floats, and ``np.asarray(x, dtype=float)``
     (and friends) of recording scalars keeps them instead of converting.  Only the attributes of
     the ``numpy`` module that user code reaches as ``np.<name>`` are replaced, only for the
-    duration of the three calls, under a lock; numpy's own internals do not go through them.  The
-    record is validated against the unmodified methods afterwards."""
+    duration of the three calls, under a lock, and they behave differently only when called from
+    the recording thread (other threads get numpy's own behaviour); numpy's own internals do not go
+    through them.  The record is validated against the unmodified methods afterwards."""
     saved = {}
+    owner = threading.get_ident()
 
     def allocator(fn):
         def wrapped(*a, **k):
             out = fn(*a, **k)
+            if threading.get_ident() != owner:
+                return out
             return out.astype(object) if isinstance(out, np.ndarray) and out.dtype.kind in "fiu" else out
         return wrapped
 
     def converter(fn):
         def wrapped(obj, *a, **k):
             dt = k.get("dtype", a[0] if a else None)
-            if _holds_sym(obj) and (dt is None or dt in _FLOAT_DTYPES or dt is object):
+            if threading.get_ident() == owner and _holds_sym(obj) and (dt is None or dt in _FLOAT_DTYPES or dt is object):
                 k.pop("dtype", None)
                 return fn(obj, *a[1:], dtype=object, **k)
             return fn(obj, *a, **k)
