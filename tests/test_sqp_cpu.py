@@ -146,3 +146,14 @@ def test_python_class_surface_and_refusal_without_gpu():
     if not torch.cuda.is_available():
         with pytest.raises(_lib.IlqrError):
             o()
+
+
+def test_sqp_problem_generator_is_shard_invariant():
+    """Problem b depends on its global index only, so ranks that build their own index range
+    (ilqr_amd.dist.shard_range) hold exactly the problems of the whole batch."""
+    whole = problems.sqp_batch(10, 40)
+    part = problems.sqp_batch(4, 40, first=3)
+    for key in ("target_states", "init_inputs", "centers", "radius"):
+        assert np.array_equal(whole[key][3:7], part[key])
+    bike = problems.bicycle_batch(6, 50)
+    assert np.array_equal(bike["target_states"][2:5], problems.bicycle_batch(3, 50, first=2)["target_states"])
