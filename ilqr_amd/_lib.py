@@ -56,7 +56,7 @@ class Buffers(C.Structure):
 class SqpOpts(C.Structure):
     _fields_ = [("max_iter", C.c_int32), ("init_input_fixed", C.c_int32), ("qp_max_iter", C.c_int32),
                 ("reserved", C.c_int32), ("eps", C.c_double), ("cost_eps", C.c_double), ("qp_tol", C.c_double),
-                ("qp_sigma", C.c_double)]
+                ("qp_sigma", C.c_double), ("x0", C.c_void_p)]
 
 
 _SIGNATURES = {
@@ -76,6 +76,7 @@ _SIGNATURES = {
     "ilqr_forward_mapping": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ilqr_forward_commit": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "ilqr_solve": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "ilqr_rollout": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ilqr_active_count": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "ilqr_to_tiled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ilqr_from_tiled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -34,6 +34,49 @@ def n_tiles(B):
     return (int(B) + _lib.TILE - 1) // _lib.TILE
 
 
+_DYNAMICS = ("model_f", "compute_df_dx", "compute_df_du")
+
+
+def _shipped_dynamics(system):
+    """True if ``system`` computes the dynamics of the shipped class that declares its
+    ``device_model_id``: neither the class nor the instance replaces one of the three methods the
+    reference would call (``ilqr.py:62``, ``:87-88``).  ``class MyCar(Car)`` with its own ``model_f``
+    must not be solved with the built-in Car kernels."""
+    from . import systems
+    for base in (systems.Car, systems.CarAcceleration, systems.DubinsCar, systems.LTVSystem):
+        if isinstance(system, base):
+            return all(getattr(type(system), name) is getattr(base, name) and name not in vars(system)
+                       for name in _DYNAMICS)
+    return False
+
+
+def resolve_model(system, dtype, constraint_mode=_lib.CONSTR_NONE):
+    """Model id of the device dynamics of ``system`` for ``ilqr_desc.model``: the built-in one of a
+    shipped class, else dynamics compiled at run time for this element type and for diagonal or
+    dense cost weights, whichever the system has: from the snippets of a ``systems.DeviceSystem``,
+    or for any other System duck type (``systems.py:4-24``) from a record of its numpy methods.
+    Recording is repeated on every call (milliseconds) so that a changed parameter the record
+    holds as a literal yields another model; compiled libraries are cached by content."""
+    np_dtype = _np_dtype(dtype)
+    model_id = getattr(system, "device_model_id", None)
+    if model_id is not None and _shipped_dynamics(system):
+        return int(model_id)
+    diag = all(np.count_nonzero(W - np.diag(np.diagonal(W))) == 0
+               for W in (np.asarray(system.Q, dtype=float), np.asarray(system.R, dtype=float),
+                         np.asarray(system.Q_f, dtype=float)))
+    if getattr(system, "device_step", None) is not None and hasattr(system, "device_model"):
+        return int(system.device_model(np_dtype, diag))
+    from . import trace
+    try:
+        # a caller that attaches constraints.py rows vouches for the (px, py, v) state layout
+        return int(trace.traced_model(system, np_dtype, diag,
+                                      has_barrier=bool(constraint_mode & _lib.CONSTR_BARRIER)
+                                      or bool(getattr(system, "device_has_barrier", False))))
+    except trace.TraceError as e:
+        raise _lib.IlqrError(f"{type(system).__name__} has no device dynamics and its numpy methods "
+                             f"could not be recorded: {e}") from e
+
+
 class DeviceProblem:
     """Device-resident state of one batched solve: the tiled trajectory/gain
     buffers, the per-problem scalars and the library handle."""
@@ -42,33 +85,15 @@ class DeviceProblem:
                  constraint_mode=_lib.CONSTR_NONE, input_limit_lambda=1e-4, barrier_mu=0.0,
                  barrier_delta=0.1, vel_bounds=(0.0, 0.0), lanes_per_problem=0, alphas_per_lane=0,
                  history=False, solver_limits=False, n_streams=0, repack_every=0, recompute_states=0,
-                 overlap_stages=0):
+                 overlap_stages=0, model_id=None, limits=None):
         torch = _torch()
         if not torch.cuda.is_available():
             raise _lib.IlqrError("no GPU visible: the batched iLQR solve runs on the HIP device only")
         self.lib = _lib.lib()
         self.device = torch.device(device if device is not None else "cuda")
         self.np_dtype = _np_dtype(dtype)
-        model_id = getattr(system, "device_model_id", None)
         if model_id is None:
-            # dynamics compiled at run time, for this element type and for diagonal or dense cost
-            # weights, whichever the system has: from the snippets of a systems.DeviceSystem, or for
-            # any other System duck type (systems.py:4-24) from a record of its numpy methods
-            diag = all(np.count_nonzero(W - np.diag(np.diagonal(W))) == 0
-                       for W in (np.asarray(system.Q, dtype=float), np.asarray(system.R, dtype=float),
-                                 np.asarray(system.Q_f, dtype=float)))
-            if hasattr(system, "device_model"):
-                model_id = system.device_model(self.np_dtype, diag)
-            else:
-                from . import trace
-                try:
-                    # a caller that attaches constraints.py rows vouches for the (px, py, v) state layout
-                    model_id = trace.traced_model(system, self.np_dtype, diag,
-                                                  has_barrier=bool(constraint_mode & _lib.CONSTR_BARRIER)
-                                                  or bool(getattr(system, "device_has_barrier", False)))
-                except trace.TraceError as e:
-                    raise _lib.IlqrError(f"{type(system).__name__} has no device dynamics and its numpy methods "
-                                         f"could not be recorded: {e}") from e
+            model_id = resolve_model(system, self.np_dtype, constraint_mode)
         self.t_dtype = torch.float64 if self.np_dtype == np.float64 else torch.float32
         self.B, self.N = int(B), int(N)
         self.n, self.m = int(system.state_size), int(system.control_size)
@@ -79,7 +104,9 @@ class DeviceProblem:
         d.B, d.N, d.n, d.m = B, N, n, m
         d.model = int(model_id)
         d.dtype = _lib.F64 if self.np_dtype == np.float64 else _lib.F32
-        d.control_limited = int(bool(system.control_limited))
+        # `limits` = (lower, upper, limited) replaces the system's control limits (a solver that
+        # keeps bounds of its own, sqp.py:38-42)
+        d.control_limited = int(bool(system.control_limited if limits is None else limits[2]))
         d.constraint_mode = int(constraint_mode)
         d.n_alphas = 0
         d.lanes_per_problem, d.alphas_per_lane = int(lanes_per_problem), int(alphas_per_lane)
@@ -104,8 +131,8 @@ class DeviceProblem:
             d.Qf[i] = v
         for i, v in enumerate(R.ravel()):
             d.R[i] = v
-        if system.control_limited or solver_limits:
-            lo, hi = system.control_lower_limit, system.control_upper_limit
+        if limits is not None or system.control_limited or solver_limits:
+            lo, hi = (system.control_lower_limit, system.control_upper_limit) if limits is None else limits[:2]
             for j in range(m):
                 d.lo[j], d.hi[j] = float(lo[j]), float(hi[j])
         self.desc = d
@@ -164,9 +191,21 @@ class DeviceProblem:
             b.ltv_A, b.ltv_B = self.ltv_A.data_ptr(), self.ltv_B.data_ptr()
         if self.hist_cost is not None:
             b.hist_cost, b.hist_alpha = self.hist_cost.data_ptr(), self.hist_alpha.data_ptr()
-            b.hist_capacity = self.max_iter
+            b.hist_capacity = int(self.hist_cost.shape[0])
         self.buffers = b
         _lib.check(self.lib.ilqr_bind(self.handle, C.byref(b)), "ilqr_bind")
+
+    def reserve_history(self, max_iter):
+        """Make the history buffers (if any) hold ``max_iter`` iterations; trajectories, gains and
+        flags stay where they are."""
+        if self.hist_cost is not None and max_iter > self.hist_cost.shape[0]:
+            torch = _torch()
+            with torch.cuda.device(self.device):
+                self.hist_cost = torch.full((max_iter, self.B), float("nan"), dtype=self.t_dtype, device=self.device)
+                self.hist_alpha = torch.full((max_iter, self.B), -2, dtype=torch.int32, device=self.device)
+            self.max_iter = max_iter
+            self._bind()
+        self.max_iter = max(self.max_iter, max_iter)
 
     def close(self):
         if getattr(self, "handle", None):
@@ -271,6 +310,19 @@ class DeviceProblem:
         mi = self.max_iter if max_iter is None else int(max_iter)
         _lib.check(self.lib.ilqr_solve(self.handle, mi, self.stream()), "ilqr_solve")
 
+    def plain_cost(self):
+        """Cost of the current device X, U for every problem (``ilqr.py:36-46`` / ``sqp.py:44-54``)."""
+        self.initial_cost()
+        return self.J.cpu().numpy().astype(np.float64)
+
+    def rollout(self, states, inputs):
+        """``sqp.py:56-61``: upload ``states`` (only step 0 matters) and ``inputs``, roll out on the
+        device, return the states ``(B, N, n)``."""
+        self._upload(states, self.X, self.N * self.n)
+        self._upload(inputs, self.U, (self.N - 1) * self.m)
+        _lib.check(self.lib.ilqr_rollout(self.handle, self.stream()), "ilqr_rollout")
+        return self.download_states()
+
     def active_count(self):
         out = C.c_int32(0)
         _lib.check(self.lib.ilqr_active_count(self.handle, self.stream(), C.byref(out)), "ilqr_active_count")
@@ -346,7 +398,8 @@ class BatchedSolverBase:
     def _key(self):
         s = self.system
         lim = (tuple(s.control_lower_limit), tuple(s.control_upper_limit)) if s.control_limited else None
-        return (self._B, self.horizon, int(self.maxIter), float(self.LM_parameter), float(s.dt),
+        self._model_id = resolve_model(s, self._dtype, self._constraint_mode)
+        return (self._B, self.horizon, self._model_id, float(self.LM_parameter), float(s.dt),
                 np.asarray(self.Q).tobytes(), np.asarray(self.R).tobytes(), np.asarray(self.Qf).tobytes(),
                 bool(s.control_limited), lim, self._alpha_floor(), repr(sorted(self._extra_desc().items())),
                 id(getattr(s, "A", None)), id(getattr(s, "B", None)))
@@ -363,8 +416,11 @@ class BatchedSolverBase:
                 lanes_per_problem=self._mapping[0], alphas_per_lane=self._mapping[1],
                 n_streams=self._n_streams, repack_every=self._repack_every,
                 recompute_states=self._recompute_states, overlap_stages=self._overlap_stages,
-                **self._extra_desc())
+                model_id=self._model_id, **self._extra_desc())
             self._dev_key = key
+        # maxIter may change between calls (the iteration count is an argument of ilqr_solve); only
+        # the history buffers are sized by it, and growing them keeps everything else on the device
+        self._dev.reserve_history(int(self.maxIter))
         return self._dev
 
     def _lead(self, a, tail_ndim):

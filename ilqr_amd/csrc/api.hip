@@ -133,7 +133,7 @@ template <bool TO_TILED> static int relayout(const void *src, void *dst, int B, 
 template <typename T>
 static hipError_t repack_launch(ilqr_handle *h, PartState &ps, int mode, hipStream_t s) {
     const ilqr_desc &d = h->ctx.d;
-    const ilqr_buffers &b = h->ctx.b;
+    const ilqr_buffers &b = ps.ctx.b;
     const WorkLayout wl = work_layout(d, true);
     char *work = (char *)b.work;
     const int N = d.N, T1 = d.N - 1, n = d.n, m = d.m;
@@ -382,6 +382,10 @@ int ilqr_bind(ilqr_handle *h, const ilqr_buffers *b) {
 #define REQUIRE_BOUND(h)                          \
     if (!(h)) return ILQR_ERR_INVALID;            \
     if (!(h)->ctx.bound) return ILQR_ERR_NOT_BOUND;
+// calls whose kernels use the caller's scratch buffer
+#define REQUIRE_WORK(h)                           \
+    REQUIRE_BOUND(h);                             \
+    if (!(h)->ctx.b.work) return ILQR_ERR_NOT_BOUND;
 
 // the handle's own stream for the second line-search stage (created on first use, on the device
 // that is current then)
@@ -422,25 +426,25 @@ static HostCtx &phase_ctx(ilqr_handle *h) {
     if ((h)->whole.packed) return ILQR_ERR_INVALID; /* ilqr_unpack first: the caller's buffers are stale */
 
 int ilqr_initial_cost(ilqr_handle *h, void *stream) {
-    REQUIRE_BOUND(h);
+    REQUIRE_WORK(h);
     REQUIRE_UNPACKED(h);
     h->ctx.reroll = false; // the caller (re)wrote X and U: X need not be the rollout of U
     return hip_rc(h->ops->cost(h->ctx, 0, (hipStream_t)stream));
 }
 
 int ilqr_backward(ilqr_handle *h, void *stream) {
-    REQUIRE_BOUND(h);
+    REQUIRE_WORK(h);
     return hip_rc(h->ops->backward(phase_ctx(h), 0, (hipStream_t)stream));
 }
 
 int ilqr_forward_evaluate(ilqr_handle *h, void *stream) {
-    REQUIRE_BOUND(h);
+    REQUIRE_WORK(h);
     if (hipError_t e = ensure_side(h); e != hipSuccess) return hip_rc(e);
     return hip_rc(h->ops->evaluate(phase_ctx(h), 0, (hipStream_t)stream));
 }
 
 int ilqr_forward_evaluate_stage(ilqr_handle *h, int32_t stage, void *stream) {
-    REQUIRE_BOUND(h);
+    REQUIRE_WORK(h);
     if (stage != 0 && stage != 1) return ILQR_ERR_INVALID;
     if (hipError_t e = ensure_side(h); e != hipSuccess) return hip_rc(e);
     HostCtx c = phase_ctx(h);
@@ -449,7 +453,7 @@ int ilqr_forward_evaluate_stage(ilqr_handle *h, int32_t stage, void *stream) {
 }
 
 int ilqr_forward_commit(ilqr_handle *h, int32_t iteration, void *stream) {
-    REQUIRE_BOUND(h);
+    REQUIRE_WORK(h);
     if (iteration < 0) return ILQR_ERR_INVALID;
     if (hipError_t e = ensure_side(h); e != hipSuccess) return hip_rc(e);
     const int rc = hip_rc(h->ops->commit(phase_ctx(h), iteration, (hipStream_t)stream));
@@ -459,14 +463,14 @@ int ilqr_forward_commit(ilqr_handle *h, int32_t iteration, void *stream) {
 }
 
 int ilqr_repack(ilqr_handle *h, void *stream) {
-    REQUIRE_BOUND(h);
+    REQUIRE_WORK(h);
     if (work_layout(h->ctx.d, h->repack_every > 0).total < work_layout(h->ctx.d, true).total) return ILQR_ERR_INVALID;
     phase_ctx(h);
     return repack(h, h->whole, REPACK_CARRY, (hipStream_t)stream);
 }
 
 int ilqr_unpack(ilqr_handle *h, void *stream) {
-    REQUIRE_BOUND(h);
+    REQUIRE_WORK(h);
     phase_ctx(h);
     const int rc = unpack(h, h->whole, (hipStream_t)stream);
     if (rc == ILQR_OK) {
@@ -482,10 +486,8 @@ int ilqr_forward(ilqr_handle *h, int32_t iteration, void *stream) {
     return ilqr_forward_commit(h, iteration, stream);
 }
 
-int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream) {
-    REQUIRE_BOUND(h);
-    if (max_iter < 0) return ILQR_ERR_INVALID;
-    REQUIRE_UNPACKED(h);
+// The iteration driver behind ilqr_solve.  `work`: the scratch buffer the kernels use for this call.
+static int solve_impl(ilqr_handle *h, int32_t max_iter, void *work, bool compaction, void *stream) {
     if (hipError_t e0 = ensure_side(h); e0 != hipSuccess) return hip_rc(e0);
     hipStream_t user = (hipStream_t)stream;
     const int np = h->n_parts;
@@ -511,8 +513,10 @@ int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream) {
     PartState part[MAX_PARTS];
     hipStream_t st[MAX_PARTS];
     h->ctx.reroll = false; // ilqr_solve starts from the caller's trajectory
-    for (int s = 0; s < np; ++s) {
+    int forked = 0; // part streams that wait on the fork event: each must be joined again, also after an error
+    for (int s = 0; s < np && rc == ILQR_OK; ++s) {
         part[s].ctx = h->ctx;
+        part[s].ctx.b.work = work;
         part[s].index = s;
         const int t0 = (int)((long)tiles * s / np), t1 = (int)((long)tiles * (s + 1) / np);
         part[s].ctx.first = t0 * TILE;
@@ -520,11 +524,11 @@ int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream) {
         part[s].ctx.count = end - part[s].ctx.first;
         st[s] = np > 1 ? h->part_stream[s] : user;
         if (np > 1) {
-            e = hipStreamWaitEvent(st[s], h->fork_event, 0);
-            if (e != hipSuccess) return hip_rc(e);
+            rc = hip_rc(hipStreamWaitEvent(st[s], h->fork_event, 0));
+            if (rc != ILQR_OK) break;
+            forked = s + 1;
         }
         rc = hip_rc(h->ops->cost(part[s].ctx, 0, st[s]));
-        if (rc != ILQR_OK) return rc;
     }
     // Launch order is iteration-major across parts.  The line search is arithmetic-bound, the
     // backward pass and the commit are bandwidth-bound; a token (an event chain) lets only one
@@ -535,7 +539,8 @@ int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream) {
         for (int s = 0; s < np && rc == ILQR_OK; ++s) {
             // from the second iteration on, every active problem's X is this library's rollout of U
             part[s].ctx.reroll = it > 0 && h->ctx.d.recompute_states >= 0;
-            if (h->repack_every > 0 && it >= 2 * h->repack_every && it % h->repack_every == 0) rc = repack(h, part[s], REPACK_CARRY, st[s]);
+            if (compaction && h->repack_every > 0 && it >= 2 * h->repack_every && it % h->repack_every == 0)
+                rc = repack(h, part[s], REPACK_CARRY, st[s]);
             if (rc == ILQR_OK) rc = hip_rc(h->ops->backward(part[s].ctx, 0, st[s]));
             if (np > 1 && use_token) {
                 if (rc == ILQR_OK && prev >= 0) rc = hip_rc(hipStreamWaitEvent(st[s], h->join_event[prev], 0));
@@ -549,13 +554,28 @@ int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream) {
         }
     for (int s = 0; s < np; ++s) {
         if (rc == ILQR_OK) rc = unpack(h, part[s], st[s]); // retire what is still in a working set
-        if (np > 1) {
+        if (np > 1 && s < forked) {
             e = hipEventRecord(h->join_event[s], st[s]);
             if (e == hipSuccess) e = hipStreamWaitEvent(user, h->join_event[s], 0);
             if (e != hipSuccess && rc == ILQR_OK) rc = hip_rc(e);
         }
     }
     return rc;
+}
+
+int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream) {
+    REQUIRE_BOUND(h);
+    if (max_iter < 0) return ILQR_ERR_INVALID;
+    REQUIRE_UNPACKED(h);
+    if (!h->ctx.b.work) return ILQR_ERR_NOT_BOUND;
+    return solve_impl(h, max_iter, h->ctx.b.work, true, stream);
+}
+
+int ilqr_rollout(ilqr_handle *h, void *stream) {
+    REQUIRE_BOUND(h);
+    REQUIRE_UNPACKED(h);
+    h->ctx.reroll = false; // X was rewritten by something other than a commit
+    return hip_rc(h->ops->rollout(h->ctx, 0, (hipStream_t)stream));
 }
 
 namespace {
@@ -568,7 +588,7 @@ __global__ void count_active_kernel(const int32_t *conv, int B, int32_t *out) {
 } // namespace
 
 int ilqr_active_count(ilqr_handle *h, void *stream, int32_t *out) {
-    REQUIRE_BOUND(h);
+    REQUIRE_WORK(h);
     if (!out) return ILQR_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     int32_t *counter = (int32_t *)((char *)h->ctx.b.work + work_layout(h->ctx.d, false).counters);
@@ -700,7 +720,7 @@ const SqpOps *sqp_check(const ilqr_handle *h, int &rc) {
         rc = ILQR_ERR_INVALID;
         return nullptr;
     }
-    if (!h->ctx.bound) {
+    if (!h->ctx.bound || !h->ctx.b.work) {
         rc = ILQR_ERR_NOT_BOUND;
         return nullptr;
     }
@@ -729,6 +749,7 @@ int sqp_args(const ilqr_handle *h, const ilqr_sqp_opts *o, void *work, const voi
     a.UQ = w + l.UQ;
     a.XQ = w + l.XQ;
     a.U0 = o->init_input_fixed ? u0 : nullptr;
+    a.X0 = o->x0;
     a.qp_iters = qp_iters;
     a.eps = o->eps;
     a.cost_eps = o->cost_eps;
@@ -775,12 +796,17 @@ int ilqr_sqp_search(ilqr_handle *h, const ilqr_sqp_opts *opts, void *work, int32
 }
 
 int ilqr_sqp_solve(ilqr_handle *h, const ilqr_sqp_opts *opts, void *work, const void *u0, int32_t *qp_iters, void *stream) {
-    int rc = ilqr_sqp_begin(h, stream);
-    for (int it = 0; rc == ILQR_OK && it < (opts ? opts->max_iter : 0); ++it) {
+    // every argument is checked before the first launch: an argument error must not touch the caller's buffers
+    int rc;
+    if (!sqp_check(h, rc)) return rc;
+    SqpArgs a;
+    rc = sqp_args(h, opts, work, u0, true, qp_iters, a);
+    if (rc != ILQR_OK) return rc;
+    rc = ilqr_sqp_begin(h, stream);
+    for (int it = 0; rc == ILQR_OK && it < opts->max_iter; ++it) {
         rc = ilqr_sqp_qp(h, opts, work, u0, qp_iters, stream);
         if (rc == ILQR_OK) rc = ilqr_sqp_search(h, opts, work, it, stream);
     }
-    if (rc == ILQR_OK && !opts) rc = ILQR_ERR_INVALID;
     return rc;
 }
 

@@ -97,6 +97,7 @@ typedef hipError_t (*probe_fn)(double dt, const void *ltvA, const void *ltvB, co
 struct ModelOps {
     launch_fn cost, backward, evaluate, commit;
     probe_fn probe;
+    launch_fn rollout; // X[t+1] = f(X[t], U[t]) from X[0] (sqp.py:56-61)
 };
 
 // What a separately compiled model library (ilqr_load_model) hands to this one.  `abi` must equal
@@ -111,7 +112,7 @@ struct PluginInfo {
     const ModelOps *(*ops)(int dtype, bool diag);
     const SqpOps *(*sqp)(int dtype); // sequential-QP kernels for this model, or a function returning null
 };
-constexpr int32_t PLUGIN_ABI_VERSION = 3;
+constexpr int32_t PLUGIN_ABI_VERSION = 4;
 static inline int32_t plugin_abi() {
     return (int32_t)(PLUGIN_ABI_VERSION * 1000003u + sizeof(HostCtx) * 31u + sizeof(ilqr_desc) * 7u + sizeof(ilqr_buffers));
 }
@@ -434,8 +435,13 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
                            (T *)fx, (T *)fu, count, t);
         return hipGetLastError();
     }
+    static hipError_t rollout(const HostCtx &c, int, hipStream_t s) {
+        auto p = make_params<T, NX, NU>(c);
+        hipLaunchKernelGGL((rollout_kernel<T, M>), dim3((c.count + 63) / 64), dim3(64), 0, s, p);
+        return hipGetLastError();
+    }
     static const ModelOps *table() {
-        static const ModelOps ops = {&cost, &backward, &evaluate, &commit, &probe};
+        static const ModelOps ops = {&cost, &backward, &evaluate, &commit, &probe, &rollout};
         return &ops;
     }
 };

@@ -685,9 +685,11 @@ template <typename T, int NX, int NU> struct StepRow { // the rows of one time s
 
 // One reverse sweep over the horizon for the problem of this lane; returns status bits and
 // sets `bad` if the fast trigonometry met an argument outside its range.
+// `store`: whether this lane writes its gains (only looked at when !FAST: the first, fast sweep
+// stores from every lane, see below; the redo sweep must leave the gains of the other lanes alone)
 template <typename T, class M, bool DIAG, int CONSTR, int PF, bool FAST, class P>
 __device__ __forceinline__ int backward_sweep(const P &p, const T *Xt, const T *Rt, const T *Ut, const T *Cp, const T *Dp,
-                                              T *Kp, T *kp, bool &bad) {
+                                              T *Kp, T *kp, bool &bad, bool store = true) {
     constexpr int NX = M::NX, NU = M::NU;
     const int T1 = p.N - 1;
     auto load_row = [&](int t, StepRow<T, NX, NU> &r) {
@@ -751,11 +753,13 @@ __device__ __forceinline__ int backward_sweep(const P &p, const T *Xt, const T *
             // changed, so they rewrite the same bits) and the padding lanes of the last tile: a
             // branch around the stores would make the number of outstanding memory operations
             // path-dependent and force full drains of the memory queue in the loop
+            if (FAST || store) {
 #pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                kp[(t * NU + i) * TILE] = kt[i];
+                for (int i = 0; i < NU; ++i) {
+                    kp[(t * NU + i) * TILE] = kt[i];
 #pragma unroll
-                for (int j = 0; j < NX; ++j) Kp[((t * NU + i) * NX + j) * TILE] = Kt[i][j];
+                    for (int j = 0; j < NX; ++j) Kp[((t * NU + i) * NX + j) * TILE] = Kt[i][j];
+                }
             }
         }
     }
@@ -787,10 +791,16 @@ __global__ __launch_bounds__(64) void backward_kernel(Params<T, M::NX, M::NU> p)
     bool bad = false;
     int status = backward_sweep<T, M, DIAG, CONSTR, PF, true>(p, Xt, Rt, Ut, Cp, Dp, Kp, kp, bad);
     // rare: an angle outside the fast trigonometric range or a Quu that is not positive definite
-    // somewhere in the wave; redo with the library sine/cosine and the pivoted-LU fallback (lanes
-    // that did not need either get the same bits as before)
-    if (__ballot(bad && active) != 0ull)
-        status = backward_sweep<T, M, DIAG, CONSTR, 1, false>(p, Xt, Rt, Ut, Cp, Dp, Kp, kp, bad);
+    // somewhere in the wave: the lanes that raised the flag redo their sweep with the library
+    // sine/cosine and the pivoted-LU fallback and replace their gains; the other lanes keep what
+    // the first sweep stored, so a problem's gains do not depend on which problems share its wave.
+    // (Lanes of converged problems count too: the first sweep has just overwritten their gains.)
+    const bool redo = bad && valid;
+    if (__ballot(redo) != 0ull) {
+        bool bad2 = false;
+        const int status2 = backward_sweep<T, M, DIAG, CONSTR, 1, false>(p, Xt, Rt, Ut, Cp, Dp, Kp, kp, bad2, redo);
+        status = redo ? status2 : status;
+    }
     if (active && status != 0 && p.status) p.status[o] |= status;
 }
 
@@ -1596,13 +1606,13 @@ __global__ __launch_bounds__(64) void evaluate_listed_kernel(Params<T, M::NX, M:
     }
     // commit (mirrors commit_kernel for these problems)
     const bool roll = active && found;
-    const bool wave_slow = __ballot(roll && pbad) != 0ull;
+    const bool slow = roll && pbad;
     if (active && al == 0) {
         const int idx = found ? best : -1;
         p.alpha_idx[o] = idx;
         p.Jtry[o] = best_cost;
         const int bits = (p.slow_trig[o] & 6) | (pbad ? 1 : 0);
-        const int committed = roll ? (4 | (wave_slow ? 2 : 0)) : 0;
+        const int committed = roll ? (4 | (slow ? 2 : 0)) : 0;
         p.slow_trig[o] = REROLL ? (bits | committed) : ((bits & 1) | committed);
         p.iters[o] += 1;
         const T Jn = roll ? best_cost : Jcur;
@@ -1620,10 +1630,9 @@ __global__ __launch_bounds__(64) void evaluate_listed_kernel(Params<T, M::NX, M:
     if (__ballot(roll) == 0ull) return;
     const T alpha = pow2_neg<T>(roll ? best : 0);
     T *Xw = tile_ptr(p.X, tile, p.N * NX, ln), *Uw = tile_ptr(p.U, tile, T1 * NU, ln);
-    if (!wave_slow)
-        listed_commit<T, M, BARRIER, L, REROLL, true>(p, pipe, Xw, Uw, alpha, roll && al == 0);
-    else
-        listed_commit<T, M, BARRIER, L, REROLL, false>(p, pipe, Xw, Uw, alpha, roll && al == 0);
+    // per problem, as in commit_kernel: the library-routine sweep writes only the problems that need it
+    if (__ballot(roll && !slow) != 0ull) listed_commit<T, M, BARRIER, L, REROLL, true>(p, pipe, Xw, Uw, alpha, roll && !slow && al == 0);
+    if (__ballot(slow) != 0ull) listed_commit<T, M, BARRIER, L, REROLL, false>(p, pipe, Xw, Uw, alpha, slow && al == 0);
 }
 
 // ---------------------------------------------------------------- line search, n = 12, m = 4, fp64
@@ -1854,9 +1863,11 @@ static __global__ __launch_bounds__(1024) void ltv12x4_evaluate_mfma_f32_kernel(
 // are known to be this code's rollout of its inputs (`keep_ok`), the recomputed states are the
 // stored bits and are written back, which keeps every store a full line; otherwise its state
 // stores go to a scratch slot `trash` (still no branch around the stores).
+// `mute`: this lane belongs to the other sweep of the kernel (fast / library trigonometry): all
+// its stores go to the scratch slot.
 template <typename T, class M, int PF, bool REROLL, bool FAST, class P>
 __device__ __forceinline__ void commit_sweep(const P &p, T *Xt, T *Ut, const T *Kp, const T *kp, T *trash, T alpha, bool roll,
-                                             bool keep_ok, bool pend) {
+                                             bool keep_ok, bool pend, bool mute) {
     constexpr int NX = M::NX, NU = M::NU;
     const int T1 = p.N - 1;
     struct Row {
@@ -1911,19 +1922,19 @@ __device__ __forceinline__ void commit_sweep(const P &p, T *Xt, T *Ut, const T *
         // which may run beside this kernel: nothing of it may be written here
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-            T *dst = pend ? trash : &Ut[(t * NU + i) * TILE];
+            T *dst = (pend || mute) ? trash : &Ut[(t * NU + i) * TILE];
             *dst = roll ? un[i] : r.up[i];
         }
         // the recomputed old states are the stored ones only while the fast trigonometry was in
         // range (the library routine may differ from it in the last bit)
-        const bool real = roll || (!pend && FAST && keep_ok && !badq);
+        const bool real = !mute && (roll || (!pend && FAST && keep_ok && !badq));
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             if (REROLL) {
                 T *dst = real ? &Xt[((t + 1) * NX + i) * TILE] : trash;
                 *dst = roll ? xn[i] : xq[i];
             } else {
-                T *dst = pend ? trash : &Xt[((t + 1) * NX + i) * TILE];
+                T *dst = (pend || mute) ? trash : &Xt[((t + 1) * NX + i) * TILE];
                 *dst = roll ? xn[i] : (t + 1 < T1 ? nxt.xp[i] : xlast[i]);
             }
         }
@@ -1957,11 +1968,10 @@ __global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, i
     // every problem, so nothing depends on what the workspace held before.
     const int slow_bits = p.slow_trig[b];
     const bool slow = roll && (slow_bits & 1) != 0;
-    const bool wave_slow = __ballot(slow) != 0ull;
     // stored states = this code's fast-path rollout of the stored inputs
     const bool keep_ok = !valid || (slow_bits & 6) == 4;
     if (valid && !pend) {
-        const int committed = roll ? (4 | (wave_slow ? 2 : 0)) : 0;
+        const int committed = roll ? (4 | (slow ? 2 : 0)) : 0;
         if (!REROLL)
             p.slow_trig[b] = (slow_bits & 1) | committed;
         else if (roll)
@@ -1983,12 +1993,13 @@ __global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, i
     }
     if (__ballot(roll) == 0ull) return;
     const T alpha = pow2_neg<T>(roll ? idx : 0);
-    // the trajectory is overwritten in place, so the choice between the fast trigonometry and
-    // the library routine is made up front, from what the evaluate kernel saw on these problems
-    if (!wave_slow)
-        commit_sweep<T, M, PF, REROLL, true>(p, Xt, Ut, Kp, kp, trash, alpha, roll, keep_ok, pend);
-    else
-        commit_sweep<T, M, 1, REROLL, false>(p, Xt, Ut, Kp, kp, trash, alpha, roll, keep_ok, pend);
+    // The trajectory is overwritten in place, so the choice between the fast trigonometry and the
+    // library routine is made up front and per problem, from what the evaluate kernel saw on it:
+    // the fast sweep writes nothing for a problem that needs the library routine, and the second
+    // sweep (rare) writes only those, so a problem's result does not depend on its wave-mates.
+    commit_sweep<T, M, PF, REROLL, true>(p, Xt, Ut, Kp, kp, trash, alpha, roll && !slow, keep_ok, pend, slow);
+    if (__ballot(slow) != 0ull)
+        commit_sweep<T, M, 1, REROLL, false>(p, Xt, Ut, Kp, kp, trash, alpha, slow, keep_ok, pend, !slow);
 }
 
 // ---------------------------------------------------------------- active-set compaction
@@ -2134,6 +2145,28 @@ __global__ __launch_bounds__(64) void model_probe_kernel(Params<T, M::NX, M::NU>
         // entries a model declares structurally zero are never read by the solver kernels
         for (int j = 0; j < NX; ++j) fx[((size_t)b * NX + i) * NX + j] = M::fx_nz(i, j) ? fxl[i][j] : T(0);
         for (int j = 0; j < NU; ++j) fu[((size_t)b * NX + i) * NU + j] = M::fu_nz(i, j) ? ful[i][j] : T(0);
+    }
+}
+
+// ---------------------------------------------------------------- plain rollout
+// sqp.py:56-61 (sim): X[t+1] = f(X[t], U[t]) from the stored X[0], one lane per problem, inputs taken
+// as they are (no clamp, no feedback).  Library sine/cosine: this is a utility, not on the solve path.
+template <typename T, class M> __global__ __launch_bounds__(64) void rollout_kernel(Params<T, M::NX, M::NU> p) {
+    constexpr int NX = M::NX, NU = M::NU;
+    const int tile = blockIdx.x, ln = threadIdx.x, T1 = p.N - 1; // buffers are padded to whole tiles
+    T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
+    const T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
+    T x[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = Xt[i * TILE];
+    bool bad = false;
+    for (int t = 0; t < T1; ++t) {
+        T u[NU], xn[NX];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) u[i] = Ut[(t * NU + i) * TILE];
+        M::template step<false>(p, t, x, u, xn, bad);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Xt[((t + 1) * NX + i) * TILE] = x[i] = xn[i];
     }
 }
 

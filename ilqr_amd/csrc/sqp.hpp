@@ -27,6 +27,7 @@ struct SqpArgs {
     void *DS, *DL, *DX; // ... of the slacks and multipliers (rows N * NR each) and of the states (rows N * NX)
     void *UQ, *XQ;     // QP iterate: inputs (rows (N-1)*NU) and states (rows N*NX); UQ ends as the solved inputs
     const void *U0;    // fixed first input (rows NU) or null (sqp.py:111-112)
+    const void *X0;    // initial state x0 (rows NX; sqp.py:37, :120, :158) or null = first row of X
     int32_t *qp_iters; // per problem: iterations of the last QP solve (may be null)
     double eps, cost_eps, qp_tol, qp_sigma;
     int32_t qp_max_iter, n_alphas, fixed;
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
     T *UQp = tile_ptr((T *)a.UQ, tile, T1 * NU, ln);
     T *XQp = tile_ptr((T *)a.XQ, tile, N * NX, ln);
     const T *U0p = a.U0 ? tile_ptr((const T *)a.U0, tile, NU, ln) : nullptr;
+    const T *X0p = a.X0 ? tile_ptr((const T *)a.X0, tile, NX, ln) : nullptr;
     const bool fixed0 = a.fixed != 0 && U0p != nullptr;
     const T sigma = (T)a.qp_sigma, tol = (T)a.qp_tol;
     using Rows = SqpRows<T, M>;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
         T x[NX], xb[NX], xbn[NX];
         load_x(Xb, 0, xb);
 #pragma unroll
-        for (int q = 0; q < NX; ++q) x[q] = xb[q];       // x0 = states[0] (sqp.py:37, :120)
+        for (int q = 0; q < NX; ++q) x[q] = X0p ? X0p[(size_t)q * TILE] : xb[q]; // x_0 = x0 (sqp.py:37, :120), linearised around states[0]
         for (int i = 0; i < N; ++i) {
             T ub[NU], u[NU];
 #pragma unroll
@@ -643,13 +645,18 @@ __global__ __launch_bounds__(64) void sqp_search_kernel(Params<T, M::NX, M::NU> 
     T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
     const T *Rt = tile_ptr(p.Xref, tile, N * NX, ln);
     const T *UQp = tile_ptr((const T *)a.UQ, tile, T1 * NU, ln);
+    const T *X0p = a.X0 ? tile_ptr((const T *)a.X0, tile, NX, ln) : nullptr;
     const T Jcur = p.J[b];
     const T eps = (T)a.eps, cost_eps = (T)a.cost_eps;
 
     auto rollout = [&](T alpha, bool store) -> T {
         T x[NX], cost = T(0);
 #pragma unroll
-        for (int q = 0; q < NX; ++q) x[q] = Xt[(size_t)q * TILE];
+        for (int q = 0; q < NX; ++q) x[q] = X0p ? X0p[(size_t)q * TILE] : Xt[(size_t)q * TILE]; // sim(self.x0, ...), sqp.py:158
+        if (store && X0p) {
+#pragma unroll
+            for (int q = 0; q < NX; ++q) Xt[(size_t)q * TILE] = x[q];
+        }
         bool bad = false;
         for (int i = 0; i < T1; ++i) {
             T u[NU], e[NX], xn[NX];

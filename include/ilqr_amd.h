@@ -184,6 +184,10 @@ int ilqr_unpack(ilqr_handle *h, void *stream);
 /* iterative_LQR.__call__ (ilqr.py:107-114): initial cost, then max_iter x
  * (backward, forward); converged problems are skipped on the device. */
 int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream);
+/* sqp.py:56-61 (sim): X[t+1] = f(X[t], U[t]) for t = 0..N-2 from the stored X[0], inputs taken as
+ * they are (no clamp).  Afterwards X is no longer a line-search result: follow with
+ * ilqr_initial_cost before any phase call. */
+int ilqr_rollout(ilqr_handle *h, void *stream);
 /* number of problems with converged == 0; synchronises `stream` */
 int ilqr_active_count(ilqr_handle *h, void *stream, int32_t *out);
 
@@ -241,6 +245,8 @@ typedef struct ilqr_sqp_opts {
     double cost_eps;           /* sqp.py:32 (1e-6): relative cost change that ends the search */
     double qp_tol;             /* complementarity and row residual at which a QP counts as solved; 0 = 1e-10 */
     double qp_sigma;           /* centring parameter of the path-following iteration; 0 = 0.1 */
+    const void *x0;            /* sqp.py:37, :120, :158: the initial state every QP and rollout starts from (device
+                                  pointer, tiled, rows = n), or NULL = the first row of X */
 } ilqr_sqp_opts;
 size_t ilqr_sqp_workspace_bytes(const ilqr_handle *h);
 int ilqr_sqp_solve(ilqr_handle *h, const ilqr_sqp_opts *opts, void *work, const void *u0, int32_t *qp_iters, void *stream);

@@ -167,18 +167,20 @@ def _interior_point(H, g, G, h, tol=1e-10, max_iter=80):
 
 
 def sqp_solve(system, constraint, target, init_inputs, max_iter=20, eps=1e-2, cost_eps=1e-6, init_input_fixed=False,
-              history=True, qp="dense"):
-    """sqp.py:136-171 for one problem.  Returns the final states/inputs and per-iteration records."""
+              history=True, qp="dense", x0=None, umin=None, umax=None):
+    """sqp.py:136-171 for one problem.  Returns the final states/inputs and per-iteration records.
+    ``x0`` / ``umin`` / ``umax``: the attributes a caller may assign after construction (sqp.py:37-42)."""
     target = np.asarray(target, dtype=float)
     inputs = np.array(init_inputs, dtype=float)
     m = system.control_size
-    x0 = target[0].copy()                                   # sqp.py:37
+    x0 = target[0].copy() if x0 is None else np.array(x0, dtype=float)   # sqp.py:37
     u0 = inputs[0].copy()                                   # sqp.py:35, :65
-    umin = np.full(m, -np.inf)
-    umax = np.full(m, np.inf)
+    lim_lo, lim_hi = np.full(m, -np.inf), np.full(m, np.inf)
     if system.control_limited:                              # sqp.py:40-42
-        umin = np.asarray(system.control_lower_limit, dtype=float)
-        umax = np.asarray(system.control_upper_limit, dtype=float)
+        lim_lo = np.asarray(system.control_lower_limit, dtype=float)
+        lim_hi = np.asarray(system.control_upper_limit, dtype=float)
+    umin = lim_lo if umin is None else np.asarray(umin, dtype=float)
+    umax = lim_hi if umax is None else np.asarray(umax, dtype=float)
     states = target.copy()                                  # sqp.py:138
     min_cost, converge = np.inf, False
     rec = dict(hist_cost=[], hist_alpha=[], hist_qp_inputs=[], hist_states=[], hist_inputs=[])

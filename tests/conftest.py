@@ -16,10 +16,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def golden_names(single=True):
+# fixtures that are not a plain "construct, assign inputs, call once" record of a shipped or
+# run-time compiled model and have tests of their own
+_SPECIAL = ("constraints_", "car_N200_warmstart", "ltv12x4_")
+
+
+def golden_names(single=True, prefix=None):
     names = []
     for f in sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))):
         name = os.path.basename(f)[:-4]
+        if prefix is not None:
+            if name.startswith(prefix):
+                names.append(name)
+            continue
+        if name.startswith(_SPECIAL):
+            continue
         batched = "batch" in name
         if single != batched:
             names.append(name)
@@ -34,7 +45,15 @@ def system_from_golden(g):
     """Rebuild the model-setup calls the fixture was generated with, on ilqr_amd.systems."""
     from ilqr_amd import systems, user_models
     name = str(g["model"])
-    s = (getattr(systems, name, None) or getattr(user_models, name))()
+    if name == "StepCountingLTV":
+        # the reference solver ran on a step-counting System over the tables of the seeded
+        # generator (oracle/make_golden.py); the tables themselves are not stored
+        from ilqr_amd import problems
+        A, Bm, _, _ = problems.ltv_system(N=g["target_states"].shape[0])
+        assert np.array_equal(np.array([A.sum(), Bm.sum()]), g["table_sums"]), "problems.ltv_system changed"
+        s = systems.LTVSystem(A, Bm, dt=float(g["dt"]))
+    else:
+        s = (getattr(systems, name, None) or getattr(user_models, name))()
     s.set_dt(float(g["dt"]))
     s.set_cost(np.array(g["Q"]), np.array(g["R"]))
     s.set_final_cost(np.array(g["Q_f"]))

@@ -704,3 +704,134 @@ def test_phase_calls_with_repack_and_unpack_equal_the_plain_solve(ilqr_cls):
         dev.initial_cost()
     dev.unpack()
     dev.initial_cost()
+
+
+# --------------------------------------------------------------------------- rare paths are per problem
+def _poisoned_pair(ilqr_cls, make_system, poison, B=130, N=60, at=70, **kw):
+    """Solve a batch twice: as generated, and with problem `at` changed by `poison(p)`.  Returns
+    (plain, poisoned, p_poisoned)."""
+    from ilqr_amd import problems
+    outs = []
+    for apply in (False, True):
+        p = problems.car_batch(B, N)
+        if apply:
+            poison(p, at)
+        s = make_system()
+        o = ilqr_cls(s, p["target_states"], s.dt, history=True, **kw)
+        o.inputs, o.states = p["init_inputs"].copy(), p["init_states"].copy()
+        o.maxIter = 6
+        o()
+        outs.append((o, p))
+    return outs[0][0], outs[1][0], outs[1][1]
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(lanes_per_problem=1, alphas_per_lane=6), dict(lanes_per_problem=4, alphas_per_lane=4)])
+def test_angle_outside_fast_trig_range_is_handled_per_problem(ilqr_cls, oracle, kw):
+    """One problem whose heading is 3e6 rad (the branch-free sine/cosine covers |x| < 2^20) makes its
+    wave repeat the sweep with the library routine.  Only that problem may take the repeated
+    result: its wave-mates must come out bit for bit as in the batch without it, and the problem
+    itself must match the oracle."""
+    at = 70
+
+    def poison(p, b):
+        p["init_states"][b, :, 3] += 3.0e6
+        p["target_states"][b, :, 3] += 3.0e6
+        p["x0"][b, 3] += 3.0e6
+
+    plain, pois, p = _poisoned_pair(ilqr_cls, demo_car_system, poison, at=at, **kw)
+    others = np.arange(plain.states.shape[0]) != at
+    for key in ("states", "inputs", "min_cost", "iterations", "converge", "status", "K", "k"):
+        assert np.array_equal(getattr(pois, key)[others], getattr(plain, key)[others]), key
+    assert np.array_equal(pois.cost_history[others], plain.cost_history[others], equal_nan=True)
+    car = demo_car_system()
+    d = oracle.make_desc(car, p["target_states"].shape[1], max_iter=6)
+    st, ui = p["init_states"][at].copy(), p["init_inputs"][at].copy()
+    r = oracle.solve(d, np.ascontiguousarray(p["target_states"][at]), st, ui)
+    n = r["iters"]
+    assert pois.iterations[at] == n and pois.status[at] == 0
+    # at 3e6 rad one ulp of the heading is 5e-10 rad: costs agree to what that allows
+    rel = np.abs(pois.cost_history[at, :n] - r["hist_cost"]) / np.abs(r["hist_cost"])
+    assert rel.max() <= 1e-6
+    assert nrm(pois.K[at], r["K_last"]) <= 1e-5
+
+
+def test_indefinite_quu_is_handled_per_problem(ilqr_cls, oracle):
+    """The cost weights are shared by the batch, so an indefinite R makes every Quu indefinite.  To
+    see that the pivoted-LU repeat of the backward sweep acts per problem, only problem `at` enters
+    active: it must get the bits it gets when everybody is active, its status bit must be set, and
+    its converged wave-mates must keep their trajectory and an empty status."""
+    from ilqr_amd import _lib, problems, systems
+    B, N, at = 100, 40, 33
+    p = problems.car_batch(B, N)
+
+    def make():
+        car = systems.Car()
+        car.set_cost(np.diag([50.0, 50.0, 1000.0, 0.0]), np.diag([-50.0, 1000.0]))   # indefinite R
+        return car
+
+    car = make()
+    # pass 1: every problem active, one backward pass: everybody takes the LU path
+    a = ilqr_cls(car, p["target_states"], car.dt)
+    a.inputs, a.states, a.maxIter = p["init_inputs"].copy(), p["init_states"].copy(), 1
+    a()
+    assert np.all(a.status & _lib.STATUS_NONPD)
+    # pass 2: only problem `at` enters active; the others are converged and must stay untouched,
+    # status included, while problem `at` gets the same bits as in pass 1
+    b = ilqr_cls(car, p["target_states"], car.dt)
+    b.inputs, b.states, b.maxIter = p["init_inputs"].copy(), p["init_states"].copy(), 1
+    conv = np.ones(B, dtype=bool)
+    conv[at] = False
+    b.converge = conv
+    b()
+    assert b.status[at] & _lib.STATUS_NONPD and not b.status[np.arange(B) != at].any()
+    assert np.array_equal(b.states[at], a.states[at]) and np.array_equal(b.K[at], a.K[at])
+    assert np.array_equal(b.states[conv], p["init_states"][conv])
+    d = oracle.make_desc(car, N, max_iter=1)
+    Ko, ko, rc = oracle.backward(d, np.ascontiguousarray(p["target_states"][at]), p["init_states"][at].copy(),
+                                 p["init_inputs"][at].copy())
+    # gains of the first (only) backward pass: K holds them for the active problem
+    assert rc == 0 and nrm(b.K[at], Ko) <= 1e-9
+
+
+def test_subclass_with_own_dynamics_is_not_solved_with_the_builtin_kernels(ilqr_cls, oracle):
+    """``class MyCar(Car)`` that overrides the dynamics must be solved with ITS dynamics (the reference
+    calls the overridden methods, ilqr.py:62, :87-88): the numpy methods are recorded and compiled."""
+    from ilqr_amd import problems, systems
+
+    class DraggedCar(systems.Car):
+        drag = 0.05
+
+        def model_f(self, x, u):
+            xn = np.array(systems.Car.model_f(self, x, u), dtype=object if x.dtype == object else float)
+            xn[2] = xn[2] - self.drag * x[2] * self.dt
+            return xn
+
+        def compute_df_dx(self, x, u):
+            J = np.array(systems.Car.compute_df_dx(self, x, u), dtype=object if x.dtype == object else float)
+            J[2, 2] = J[2, 2] - self.drag * self.dt
+            return J
+
+    p = problems.car_batch(3, 50)
+    outs = {}
+    for cls in (systems.Car, DraggedCar):
+        s = cls()
+        s.set_cost(problems.CAR_Q.copy(), problems.CAR_R.copy())
+        s.set_control_limit(*problems.CAR_LIMITS)
+        o = ilqr_cls(s, p["target_states"], s.dt, history=True)
+        o.inputs, o.states, o.maxIter = p["init_inputs"].copy(), p["init_states"].copy(), 5
+        o()
+        outs[cls.__name__] = (o, s)
+    o, s = outs["DraggedCar"]
+    assert not np.allclose(o.min_cost, outs["Car"][0].min_cost, rtol=1e-6)
+    d = oracle.make_desc(s, 50, max_iter=5)          # calls the subclass's numpy methods back
+    r = oracle.solve_batch(d, p["target_states"], p["init_states"].copy(), p["init_inputs"].copy())
+    assert (np.abs(o.cost_history[:, :5] - r["hist_cost"]) / r["hist_cost"]).max() <= 1e-9
+    # a parameter the record holds as a literal: changing it must rebuild, not reuse the old model
+    s.drag = 0.2
+    o2 = ilqr_cls(s, p["target_states"], s.dt, history=True)
+    o2.inputs, o2.states, o2.maxIter = p["init_inputs"].copy(), p["init_states"].copy(), 5
+    o2()
+    assert not np.allclose(o2.min_cost, o.min_cost, rtol=1e-6)
+    o.inputs, o.states, o.converge = p["init_inputs"].copy(), p["init_states"].copy(), np.zeros(3, dtype=bool)
+    o()                                               # the SAME solver object notices the change too
+    assert np.array_equal(o.min_cost, o2.min_cost)
