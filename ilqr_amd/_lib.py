@@ -11,6 +11,7 @@ MAX_N, MAX_M = 12, 4
 MODEL_USER_BASE = 16
 F64, F32 = 0, 1
 CONSTR_NONE, CONSTR_BOXQP, CONSTR_BARRIER = 0, 1, 2
+STATIC_MAX_PROBLEMS = 65536
 STATUS_NONPD, STATUS_SINGULAR, STATUS_NONFINITE, STATUS_QP_FAILED = 1, 2, 4, 8
 TILE = 64
 
@@ -76,6 +77,7 @@ _SIGNATURES = {
     "ilqr_forward_mapping": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ilqr_forward_commit": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "ilqr_solve": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "ilqr_solve_static": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "ilqr_rollout": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ilqr_active_count": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "ilqr_to_tiled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -310,6 +310,11 @@ class DeviceProblem:
         mi = self.max_iter if max_iter is None else int(max_iter)
         _lib.check(self.lib.ilqr_solve(self.handle, mi, self.stream()), "ilqr_solve")
 
+    def solve_static(self, max_iter=None):
+        """``ilqr_solve`` on the library's own static scratch (allocates nothing)."""
+        mi = self.max_iter if max_iter is None else int(max_iter)
+        _lib.check(self.lib.ilqr_solve_static(self.handle, mi, self.stream()), "ilqr_solve_static")
+
     def plain_cost(self):
         """Cost of the current device X, U for every problem (``ilqr.py:36-46`` / ``sqp.py:44-54``)."""
         self.initial_cost()

@@ -46,6 +46,19 @@ struct ilqr_handle {
 
 static thread_local int g_last_hip_error = 0;
 
+// ---- scratch of ilqr_solve_static ---------------------------------------------------------------
+// One array per GPU, in the library's own device image, so that the entry point never allocates.
+// `scratch` is only a host-side stand-in for the symbol: the device address is looked up once per
+// device (each GPU holds its own copy at its own address) and that pointer is what every launch,
+// memset and copy gets.
+constexpr size_t STATIC_SCRATCH_BYTES = 1843200; // work_layout() of ILQR_STATIC_MAX_PROBLEMS fp64 problems, rounded up
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+void *g_scratch_ptr[MAX_DEVICES];
+} // namespace
+
 // Model libraries loaded at run time (ilqr_load_model).  Entries are never removed: handles keep
 // pointers into the launch tables of the library they were created from.
 namespace {
@@ -365,7 +378,8 @@ int ilqr_forward_mapping(const ilqr_handle *h, int32_t *lanes_per_problem, int32
 
 int ilqr_bind(ilqr_handle *h, const ilqr_buffers *b) {
     if (!h || !b) return ILQR_ERR_INVALID;
-    if (!b->X || !b->U || !b->Xref || !b->K || !b->k || !b->J || !b->converged || !b->iters || !b->alpha_idx || !b->work)
+    // `work` may be NULL for a caller that only uses ilqr_solve_static; every other call checks it
+    if (!b->X || !b->U || !b->Xref || !b->K || !b->k || !b->J || !b->converged || !b->iters || !b->alpha_idx)
         return ILQR_ERR_NOT_BOUND;
     if ((h->ctx.d.constraint_mode & ILQR_CONSTR_BARRIER) && (!b->centers || !b->radius)) return ILQR_ERR_NOT_BOUND;
     if (h->ctx.d.model == ILQR_MODEL_LTV && (!b->ltv_A || !b->ltv_B)) return ILQR_ERR_NOT_BOUND;
@@ -486,7 +500,8 @@ int ilqr_forward(ilqr_handle *h, int32_t iteration, void *stream) {
     return ilqr_forward_commit(h, iteration, stream);
 }
 
-// The iteration driver behind ilqr_solve.  `work`: the scratch buffer the kernels use for this call.
+// The iteration driver behind ilqr_solve and ilqr_solve_static.  `work`: the scratch buffer the
+// kernels use for this call (the bound one, or the library's own static array).
 static int solve_impl(ilqr_handle *h, int32_t max_iter, void *work, bool compaction, void *stream) {
     if (hipError_t e0 = ensure_side(h); e0 != hipSuccess) return hip_rc(e0);
     hipStream_t user = (hipStream_t)stream;
@@ -569,6 +584,36 @@ int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream) {
     REQUIRE_UNPACKED(h);
     if (!h->ctx.b.work) return ILQR_ERR_NOT_BOUND;
     return solve_impl(h, max_iter, h->ctx.b.work, true, stream);
+}
+
+int ilqr_solve_static(ilqr_handle *h, int32_t max_iter, void *stream) {
+    REQUIRE_BOUND(h);
+    if (max_iter < 0) return ILQR_ERR_INVALID;
+    REQUIRE_UNPACKED(h);
+    // streams and events of its own would have to be created: not in a call that must not allocate
+    if (h->n_parts > 1 || h->overlap) return ILQR_ERR_UNSUPPORTED;
+    const size_t need = work_layout(h->ctx.d, false).total;
+    if (h->ctx.d.B > ILQR_STATIC_MAX_PROBLEMS || need > STATIC_SCRATCH_BYTES) return ILQR_ERR_TOO_LARGE;
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_rc(e);
+    if (dev < 0 || dev >= MAX_DEVICES) return ILQR_ERR_UNSUPPORTED;
+    void *ptr = nullptr;
+    {
+        // set-up, once per device, with that device current: the address of this GPU's copy of the array
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[dev]) {
+            void *sym = nullptr;
+            e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !sym) return hip_rc(e != hipSuccess ? e : hipErrorInvalidSymbol);
+            g_scratch_ptr[dev] = sym;
+        }
+        ptr = g_scratch_ptr[dev];
+    }
+    // the array keeps what the last call left in it: start from zeros
+    e = hipMemsetAsync(ptr, 0, need, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_rc(e);
+    return solve_impl(h, max_iter, ptr, false, stream);
 }
 
 int ilqr_rollout(ilqr_handle *h, void *stream) {
@@ -817,6 +862,7 @@ const char *ilqr_strerror(int code) {
     case ILQR_ERR_UNSUPPORTED: return "model/dtype/shape combination not built into this library";
     case ILQR_ERR_NOT_BOUND: return "a required device buffer is not bound";
     case ILQR_ERR_HIP: return "HIP runtime error (see ilqr_last_hip_error)";
+    case ILQR_ERR_TOO_LARGE: return "batch exceeds the static scratch of ilqr_solve_static (ILQR_STATIC_MAX_PROBLEMS problems)";
     default: return "unknown error code";
     }
 }

@@ -48,7 +48,8 @@ typedef enum ilqr_status {
     ILQR_ERR_INVALID = -1,     /* bad descriptor field or NULL pointer */
     ILQR_ERR_UNSUPPORTED = -2, /* combination not built (model/dtype/shape) */
     ILQR_ERR_NOT_BOUND = -3,   /* a required buffer was not bound */
-    ILQR_ERR_HIP = -4          /* a HIP runtime call failed (see ilqr_last_hip_error) */
+    ILQR_ERR_HIP = -4,         /* a HIP runtime call failed (see ilqr_last_hip_error) */
+    ILQR_ERR_TOO_LARGE = -5    /* ilqr_solve_static: more problems than its static scratch holds */
 } ilqr_status;
 
 /* device dynamics: systems.py:27-57 / :59-90 / :92-121; LTV has no reference counterpart */
@@ -122,7 +123,7 @@ typedef struct ilqr_buffers {
     int32_t *iters;          /* in/out: backward+forward pairs executed */
     int32_t *alpha_idx;      /* out: accepted step index of the last forward pass, -1 = none */
     int32_t *status;         /* in/out: ILQR_STATUS_* bits, or NULL */
-    void *work;              /* scratch of ilqr_workspace_bytes() */
+    void *work;              /* scratch of ilqr_workspace_bytes(); may be NULL if only ilqr_solve_static is used */
     const void *centers, *radius; /* barrier mode only */
     const void *ltv_A, *ltv_B;    /* ILQR_MODEL_LTV: [N-1][n][n], [N-1][n][m], shared by the batch; a model loaded at
                                      run time may read them as parameter tables of its own layout */
@@ -184,6 +185,19 @@ int ilqr_unpack(ilqr_handle *h, void *stream);
 /* iterative_LQR.__call__ (ilqr.py:107-114): initial cost, then max_iter x
  * (backward, forward); converged problems are skipped on the device. */
 int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream);
+/* ilqr_solve for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same results
+ * as ilqr_solve, bit for bit, but the kernels' scratch (what ilqr_buffers.work otherwise brings in:
+ * trial costs, the list of the second line-search stage, counters) lives in an array inside the
+ * library's device image, one copy per GPU, held until the process ends (1.8 MB), so the handle may
+ * be bound with work = NULL.  The call allocates and frees nothing and runs no active-set
+ * compaction.  Limits: at most ILQR_STATIC_MAX_PROBLEMS problems per handle (ILQR_ERR_TOO_LARGE
+ * beyond that); n_streams <= 1 and overlap_stages <= 0 (ILQR_ERR_UNSUPPORTED otherwise).  The
+ * first call on a GPU looks the array's address up; make it outside any graph capture.  All calls
+ * on one GPU share that GPU's array: calls that overlap in time on one GPU (different streams or
+ * threads) race and must be serialised by the caller.  Device = the one current at the call. */
+#define ILQR_STATIC_MAX_PROBLEMS 65536
+int ilqr_solve_static(ilqr_handle *h, int32_t max_iter, void *stream);
 /* sqp.py:56-61 (sim): X[t+1] = f(X[t], U[t]) for t = 0..N-2 from the stored X[0], inputs taken as
  * they are (no clamp).  Afterwards X is no longer a line-search result: follow with
  * ilqr_initial_cost before any phase call. */
