@@ -9,9 +9,11 @@ One *step* = one complete batched solve (``iterative_LQR.__call__``: initial cos
 30 backward/forward iterations per problem until its ``converge`` flag) of B Car problems with
 horizon N=200 in fp64, the configuration the headline metric is quoted on.  Inputs are
 resident in HBM when the timed region starts; every step restores the initial guess with a
-device-to-device copy (inside the timed region) and solves again.  With N GPUs every rank
-solves its own B problems (weak scaling, no communication on the solve path); the reported
-value is the whole-job rate.
+device-to-device copy (inside the timed region) and solves again.  With N > 1 GPUs the batch of
+65536 problems is split by problem index into contiguous shards, one per rank (strong scaling,
+the configuration the metric names: 32768 / 16384 / 8192 problems per GPU at N = 2 / 4 / 8; no
+communication on the solve path); ``--weak`` gives every rank its own ``--batch`` problems
+instead.  The reported value is the whole-job rate.
 
 Prints ONE JSON line on rank 0 with the metric, a ``roofline`` object for the dominant kernel
 (the one with the largest total time; per-launch HIP-event timings taken inside the timed region,
@@ -53,12 +55,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=65536, help="problems per GPU")
+    ap.add_argument("--batch", type=int, default=65536, help="problems of the whole job (per GPU with --weak)")
     ap.add_argument("--horizon", type=int, default=200)
-    ap.add_argument("--strong", action="store_true", help="split --batch over the GPUs instead of per-GPU")
+    ap.add_argument("--weak", action="store_true", help="every GPU solves --batch problems of its own instead of a shard")
+    ap.add_argument("--strong", action="store_true", help="(default) split --batch over the GPUs by problem index")
     ap.add_argument("--mapping", default="auto", help="forward mapping L,A (lanes per problem, step sizes per lane)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--repack-every", type=int, default=8, help="active-set compaction period (what ilqr_solve uses for this batch size)")
+    ap.add_argument("--repack-every", type=int, default=None,
+                    help="active-set compaction period; default = what ilqr_solve picks: 8 from 32768 problems per GPU on, else none")
     ap.add_argument("--no-repack", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=65536, help="upper bound on problems in the CPU baseline sample")
@@ -78,11 +82,7 @@ def main():
     idist.init_process_group("nccl" if world > 1 else None)
 
     N = args.horizon
-    if args.strong:
-        first, B = idist.shard_range(args.batch, rank, world)
-        B_total = args.batch
-    else:
-        B, first, B_total = args.batch, rank * args.batch, args.batch * world
+    first, B, B_total = bench_shard(args.batch, rank, world, args.weak)
     car = systems.Car()
     car.set_dt(0.2)
     car.set_cost(problems.CAR_Q.copy(), problems.CAR_R.copy())
@@ -94,7 +94,10 @@ def main():
         L, A = (int(v) for v in args.mapping.split(","))
         kw = dict(lanes_per_problem=L, alphas_per_lane=A)
     np_dtype = np.float64 if args.dtype == "f64" else np.float32
-    opt = iterative_LQR(car, p["target_states"], car.dt, history=True, dtype=np_dtype, **kw)
+    repack_every = 0 if args.no_repack else (args.repack_every if args.repack_every is not None else (8 if B >= 32768 else 0))
+    # the handle is created with the same period, so that it holds the workspace ilqr_repack needs
+    opt = iterative_LQR(car, p["target_states"], car.dt, history=True, dtype=np_dtype,
+                        repack_every=repack_every if repack_every > 0 else -1, **kw)
     opt.inputs, opt.states = p["init_inputs"], p["init_states"]
     dev = opt.upload()
     X0, U0 = dev.X.clone(), dev.U.clone()
@@ -111,8 +114,6 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-
-    repack_every = 0 if args.no_repack else args.repack_every
 
     def solve_step(events=None):
         """The launches of ilqr_solve, issued one by one so that events can bracket them."""
@@ -152,6 +153,14 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
+
+    # cross-check, outside the timed region: the same solve issued by the single C call
+    reset()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    dev.solve(max_iter)
+    torch.cuda.synchronize()
+    ilqr_solve_ms = 1e3 * (time.perf_counter() - t1)
 
     # per-problem outcome of the last step (identical every step: same inputs)
     iters = dev.iters.cpu().numpy()
@@ -203,7 +212,7 @@ def main():
     if rank == 0:
         solves = float(B_total) * args.steps
         out = {
-            "metric": "batched iLQR solves/sec (B=65536, N=200)",
+            "metric": f"batched iLQR solves/sec (B={B_total}, N={N})",
             "value": solves / elapsed,
             "unit": "solves/s",
             "n_gpus": world,
@@ -211,11 +220,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "strong" if args.strong else "weak",
+            "scaling": "weak" if args.weak else "strong",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic (seeded Car tracking problems, ilqr_amd.problems.car_batch)",
-            "config": {"workload": f"Car n=4 m=2, N={N}, B={B} problems per GPU, maxIter=30, 15 parallel step sizes",
+            "config": {"workload": f"Car n=4 m=2, N={N}, B={B_total} problems"
+                                   + (f" sharded by problem index over {world} GPUs ({B} per GPU)" if world > 1 and not args.weak
+                                      else f" on each of {world} GPUs" if world > 1 else "")
+                                   + ", maxIter=30, 15 parallel step sizes",
                        "batch_per_gpu": B, "batch_total": B_total, "horizon": N,
                        "forward_mapping": f"L={L_},A={A_} ({'two-stage' if L_ * A_ < n_alphas else 'one stage'})",
                        "active_set_compaction_every": repack_every},
@@ -232,7 +244,8 @@ def main():
             "kernels": kernels,
             "solve_achieved_GBs": float(args.steps * (active * (ab["backward"] + ab["evaluate_first"]) + listed * ab["evaluate_rest"]
                                                       + accepted * ab["commit"]).sum()
-                                        / elapsed / 1e9) * (world if not args.strong else 1),
+                                        / elapsed / 1e9) * world,   # rank 0's shard x ranks (shards are equal up to one tile)
+            "ilqr_solve_ms": ilqr_solve_ms,     # one ilqr_solve() call on the same inputs (host clock, rank 0, untimed region)
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(car, p, N, args.cpu_sample)
@@ -240,6 +253,30 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_shard(batch, rank, world, weak):
+    """(first problem, problems of this rank, problems of the whole job)."""
+    from ilqr_amd import dist as idist
+    if weak:
+        return rank * batch, batch, batch * world
+    first, count = idist.shard_range(batch, rank, world)
+    return first, count, batch
+
+
+def reference_calibration():
+    """The measured ratio between the C port and the numpy reference (tools/time_reference.py, build
+    container), or None if the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r02", "cpu_reference.json")
+    try:
+        with open(path) as f:
+            c = json.load(f)
+        return {"file": "profiles/r02/cpu_reference.json", "where": c["where"], "cpu": c["cpu"],
+                "reference_solves_per_s_per_core": c["reference"]["solves_per_s_per_core"],
+                "c_port_solves_per_s_per_core": c["c_port"]["solves_per_s_per_core"],
+                "port_over_reference_per_core": c["port_over_reference_per_core"]}
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(car, p, N, sample):
@@ -262,11 +299,16 @@ def cpu_baseline(car, p, N, sample):
     t0 = time.perf_counter()
     r = oracle.solve_batch(d, tg[:sample], st, ui, nthreads=cores, history=False)
     el = time.perf_counter() - t0
-    return {"value": sample / el, "unit": "solves/s", "cores": cores, "kind": "port",
-            "sample": f"first {sample} problems of the same batch, C oracle (scalar fp64 port of ilqr.py), "
-                      f"OpenMP over problems, {el:.1f} s wall, mean {float(r['iters'].mean()):.1f} iterations",
-            "note": "the reference itself (numpy ilqr.py) ran the same problems at 1.10 solves/s per core in the build "
-                    "container, 280x slower per core than this port; it cannot travel to the GPU box"}
+    out = {"value": sample / el, "unit": "solves/s", "cores": cores, "kind": "port",
+           "sample": f"first {sample} problems of the same batch, C oracle (scalar fp64 port of ilqr.py), "
+                     f"OpenMP over problems, {el:.1f} s wall, mean {float(r['iters'].mean()):.1f} iterations"}
+    cal = reference_calibration()
+    if cal is not None:
+        # the reference (numpy ilqr.py) cannot travel to the GPU box: its speed relative to this port
+        # was measured where both exist
+        out["reference_calibration"] = cal
+        out["reference_equivalent_value"] = out["value"] / cal["port_over_reference_per_core"]
+    return out
 
 
 if __name__ == "__main__":

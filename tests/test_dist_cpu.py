@@ -66,3 +66,18 @@ def test_two_rank_sharded_solve_matches_single_rank(tmp_path, oracle):
         assert np.array_equal(got["cost"], ref["min_cost"])
         assert np.array_equal(got["iters"], ref["iters"])
         assert np.array_equal(got["conv"], ref["converge"])
+
+
+def test_bench_shards_are_the_strong_scaling_configuration():
+    """bench.py --gpus N splits the 65536 problems of the headline configuration by problem index:
+    32768 / 16384 / 8192 per GPU at N = 2 / 4 / 8, contiguous and complete; --weak keeps --batch per GPU."""
+    import bench
+    for world, per in ((1, 65536), (2, 32768), (4, 16384), (8, 8192)):
+        shards = [bench.bench_shard(65536, r, world, weak=False) for r in range(world)]
+        assert all(s[1] == per and s[2] == 65536 for s in shards)
+        assert [s[0] for s in shards] == [r * per for r in range(world)]
+    assert bench.bench_shard(4096, 3, 8, weak=True) == (3 * 4096, 4096, 8 * 4096)
+    # ragged totals stay complete and contiguous
+    shards = [bench.bench_shard(1000, r, 3, weak=False) for r in range(3)]
+    assert sum(s[1] for s in shards) == 1000 and shards[0][0] == 0
+    assert all(shards[i][0] + shards[i][1] == shards[i + 1][0] for i in range(2))
