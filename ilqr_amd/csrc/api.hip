@@ -32,6 +32,7 @@ struct ilqr_handle {
     // part's arithmetic-bound line search overlaps another part's bandwidth-bound passes
     int n_parts = 1;
     int repack_every = 0;   // 0: no compaction
+    bool trig = false;      // sine/cosine cache in `work` (HostCtx::trig)
     // the phase calls (ilqr_backward ...) and the single-stream ilqr_solve work on the whole batch as
     // one part whose compaction state lives here, between calls
     PartState whole;
@@ -342,6 +343,14 @@ int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
         // the latency of a time step, where it cannot
         h->repack_every = d.repack_every > 0 ? d.repack_every : (d.repack_every == 0 && d.B >= 32768 ? 8 : 0);
     }
+    // Sine/cosine cache: 0 = auto.  Up to 16384 problems the passes are bound by their instruction
+    // stream (one wave per SIMD or fewer), a third of which is the sine/cosine of the heading; above,
+    // by bandwidth, where 16 more bytes per step and pass cost more than the instructions saved.
+    // Not with compaction (the cache is not carried into the working sets) nor beside a second
+    // line-search stage that commits on its own.
+    h->trig = ops->trig_pairs == 1 && h->repack_every == 0 && d.recompute_states >= 0 && d.overlap_stages <= 0 &&
+              (d.trig_cache > 0 || (d.trig_cache == 0 && d.B <= 16384));
+    h->ctx.trig = h->trig;
     // off unless asked for: beside the bandwidth-bound commit the latency-bound second stage runs
     // 2.5x slower and slows the commit down (measured: 34.8 -> 42.0 ms per solve at B = 65536)
     h->overlap = d.overlap_stages > 0 && h->n_parts == 1;
@@ -365,7 +374,7 @@ void ilqr_destroy(ilqr_handle *h) {
 }
 
 // layout of `work`: see work_layout() in host.hpp
-size_t ilqr_workspace_bytes(const ilqr_handle *h) { return h ? work_layout(h->ctx.d, h->repack_every > 0).total : 0; }
+size_t ilqr_workspace_bytes(const ilqr_handle *h) { return h ? work_layout(h->ctx.d, h->repack_every > 0, h->trig).total : 0; }
 
 int32_t ilqr_num_alphas(const ilqr_handle *h) { return h ? h->ctx.n_alphas : 0; }
 
@@ -429,6 +438,7 @@ static HostCtx &phase_ctx(ilqr_handle *h) {
     h->whole.ctx.count = h->ctx.d.B;
     h->whole.ctx.reroll = h->ctx.reroll;
     h->whole.ctx.select_converged = false;
+    h->whole.ctx.trig = h->trig;
     h->whole.ctx.eval_stages = 3;
     h->whole.ctx.side = h->ctx.side;
     h->whole.ctx.ev_fork = h->ctx.ev_fork;
@@ -478,7 +488,7 @@ int ilqr_forward_commit(ilqr_handle *h, int32_t iteration, void *stream) {
 
 int ilqr_repack(ilqr_handle *h, void *stream) {
     REQUIRE_WORK(h);
-    if (work_layout(h->ctx.d, h->repack_every > 0).total < work_layout(h->ctx.d, true).total) return ILQR_ERR_INVALID;
+    if (h->repack_every <= 0) return ILQR_ERR_INVALID; // the handle's workspace holds no working sets
     phase_ctx(h);
     return repack(h, h->whole, REPACK_CARRY, (hipStream_t)stream);
 }
@@ -502,7 +512,7 @@ int ilqr_forward(ilqr_handle *h, int32_t iteration, void *stream) {
 
 // The iteration driver behind ilqr_solve and ilqr_solve_static.  `work`: the scratch buffer the
 // kernels use for this call (the bound one, or the library's own static array).
-static int solve_impl(ilqr_handle *h, int32_t max_iter, void *work, bool compaction, void *stream) {
+static int solve_impl(ilqr_handle *h, int32_t max_iter, void *work, bool compaction, bool trig, void *stream) {
     if (hipError_t e0 = ensure_side(h); e0 != hipSuccess) return hip_rc(e0);
     hipStream_t user = (hipStream_t)stream;
     const int np = h->n_parts;
@@ -532,6 +542,7 @@ static int solve_impl(ilqr_handle *h, int32_t max_iter, void *work, bool compact
     for (int s = 0; s < np && rc == ILQR_OK; ++s) {
         part[s].ctx = h->ctx;
         part[s].ctx.b.work = work;
+        part[s].ctx.trig = trig;
         part[s].index = s;
         const int t0 = (int)((long)tiles * s / np), t1 = (int)((long)tiles * (s + 1) / np);
         part[s].ctx.first = t0 * TILE;
@@ -583,7 +594,7 @@ int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream) {
     if (max_iter < 0) return ILQR_ERR_INVALID;
     REQUIRE_UNPACKED(h);
     if (!h->ctx.b.work) return ILQR_ERR_NOT_BOUND;
-    return solve_impl(h, max_iter, h->ctx.b.work, true, stream);
+    return solve_impl(h, max_iter, h->ctx.b.work, true, h->trig, stream);
 }
 
 int ilqr_solve_static(ilqr_handle *h, int32_t max_iter, void *stream) {
@@ -613,7 +624,7 @@ int ilqr_solve_static(ilqr_handle *h, int32_t max_iter, void *stream) {
     // the array keeps what the last call left in it: start from zeros
     e = hipMemsetAsync(ptr, 0, need, (hipStream_t)stream);
     if (e != hipSuccess) return hip_rc(e);
-    return solve_impl(h, max_iter, ptr, false, stream);
+    return solve_impl(h, max_iter, ptr, false, false, stream); // the static array has no room for the sine/cosine cache
 }
 
 int ilqr_rollout(ilqr_handle *h, void *stream) {

@@ -21,6 +21,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace ilqr {
 
@@ -100,6 +101,7 @@ constexpr int TILE = 64;
 #ifndef EVAL_MIN_WAVES
 #define EVAL_MIN_WAVES 1
 #endif
+
 template <typename T> __device__ __forceinline__ T *tile_ptr(T *base, int tile, int rows, int lane) {
     return base + (size_t)tile * (size_t)rows * TILE + lane;
 }
@@ -129,6 +131,14 @@ template <typename T, int NX, int NU> struct Params {
     const int32_t *carried; // per problem: was ever copied into a working set (select_converged only)
     int32_t *redo; // per problem: the backward pass must be repeated with the pivoted-LU solve (n = 12 model)
     T *trash; // 64 values per tile: where lanes that must not change their trajectory store (commit, REROLL)
+    // Sine/cosine cache (null = off): tiled, rows = (N-1) * 2 (sine, cosine of the model's shared angle
+    // at the stored state of every time step).  Written by every commit for the problems it rolls
+    // out; valid for the problems that are still iterating once a step has been committed
+    // (the condition under which the forward kernels also roll the previous states out again), and
+    // then read by the backward pass and the line search instead of evaluating the functions again:
+    // a third of all instructions of a Car iteration.  Costs 16 bytes of traffic per step and pass,
+    // so it pays where the passes are bound by their instruction stream (small batches).
+    T *SC;
     const T *centers, *radius;
     const T *ltvA, *ltvB;
     T *hist_cost;
@@ -151,25 +161,26 @@ template <typename T, int NX, int NU> struct Params {
 // order of the reference (x + rate*dt) and declares which Jacobian entries can
 // be non-zero, so the generic Riccati code skips structural zeros at compile time.
 
+// A model whose step() and jac() need the sine and cosine of ONE angle of (x, u) may say so
+// (NT = 1, trig_arg, step_sc, jac_sc): the kernels can then keep the pair of every time step of the
+// committed trajectory in memory and hand it back instead of evaluating it again (see Params::SC).
 template <typename T> struct CarModel { // systems.py:27-57
     static constexpr int NX = 4, NU = 2;
+    static constexpr int NT = 1;
     static constexpr bool HAS_BARRIER = true; // state layout of constraints.py:12 (px, py, v, .)
     static constexpr bool fx_nz(int i, int j) { return i == j || (i < 2 && j >= 2); }
     static constexpr bool fx_one(int i, int j) { return i == j; }
     static constexpr bool fu_nz(int i, int j) { return (i == 2 && j == 0) || (i == 3 && j == 1); }
-    template <bool FAST, class P>
-    static __device__ __forceinline__ void step(const P &p, int, const T (&x)[NX], const T (&u)[NU], T (&xn)[NX], bool &bad) {
-        T s, c;
-        sincos_<FAST>(x[3], s, c, bad);
+    static __device__ __forceinline__ T trig_arg(const T (&x)[NX], const T (&)[NU]) { return x[3]; }
+    template <class P>
+    static __device__ __forceinline__ void step_sc(const P &p, int, const T (&x)[NX], const T (&u)[NU], T (&xn)[NX], T s, T c) {
         xn[0] = fma_(x[2] * c, p.dt, x[0]);
         xn[1] = fma_(x[2] * s, p.dt, x[1]);
         xn[2] = fma_(u[0], p.dt, x[2]);
         xn[3] = fma_(u[1], p.dt, x[3]);
     }
-    template <bool FAST, class P>
-    static __device__ __forceinline__ void jac(const P &p, int, const T (&x)[NX], const T (&)[NU], T (&fx)[NX][NX], T (&fu)[NX][NU], bool &bad) {
-        T s, c;
-        sincos_<FAST>(x[3], s, c, bad);
+    template <class P>
+    static __device__ __forceinline__ void jac_sc(const P &p, int, const T (&x)[NX], const T (&)[NU], T (&fx)[NX][NX], T (&fu)[NX][NU], T s, T c) {
         fx[0][2] = c * p.dt;
         fx[0][3] = (-s * x[2]) * p.dt;
         fx[1][2] = s * p.dt;
@@ -177,28 +188,38 @@ template <typename T> struct CarModel { // systems.py:27-57
         fu[2][0] = p.dt;
         fu[3][1] = p.dt;
     }
+    template <bool FAST, class P>
+    static __device__ __forceinline__ void step(const P &p, int t, const T (&x)[NX], const T (&u)[NU], T (&xn)[NX], bool &bad) {
+        T s, c;
+        sincos_<FAST>(x[3], s, c, bad);
+        step_sc(p, t, x, u, xn, s, c);
+    }
+    template <bool FAST, class P>
+    static __device__ __forceinline__ void jac(const P &p, int t, const T (&x)[NX], const T (&u)[NU], T (&fx)[NX][NX], T (&fu)[NX][NU], bool &bad) {
+        T s, c;
+        sincos_<FAST>(x[3], s, c, bad);
+        jac_sc(p, t, x, u, fx, fu, s, c);
+    }
 };
 
 template <typename T> struct CarAccModel { // systems.py:59-90
     static constexpr int NX = 5, NU = 2;
+    static constexpr int NT = 1;
     static constexpr bool HAS_BARRIER = false;
     static constexpr bool fx_nz(int i, int j) { return i == j || (i < 2 && (j == 2 || j == 4)) || (i == 2 && j == 3); }
     static constexpr bool fx_one(int i, int j) { return i == j; }
     static constexpr bool fu_nz(int i, int j) { return (i == 3 && j == 0) || (i == 4 && j == 1); }
-    template <bool FAST, class P>
-    static __device__ __forceinline__ void step(const P &p, int, const T (&x)[NX], const T (&u)[NU], T (&xn)[NX], bool &bad) {
-        T s, c;
-        sincos_<FAST>(x[4], s, c, bad);
+    static __device__ __forceinline__ T trig_arg(const T (&x)[NX], const T (&)[NU]) { return x[4]; }
+    template <class P>
+    static __device__ __forceinline__ void step_sc(const P &p, int, const T (&x)[NX], const T (&u)[NU], T (&xn)[NX], T s, T c) {
         xn[0] = fma_(x[2] * c, p.dt, x[0]);
         xn[1] = fma_(x[2] * s, p.dt, x[1]);
         xn[2] = fma_(x[3], p.dt, x[2]);
         xn[3] = fma_(u[0], p.dt, x[3]);
         xn[4] = fma_(u[1], p.dt, x[4]);
     }
-    template <bool FAST, class P>
-    static __device__ __forceinline__ void jac(const P &p, int, const T (&x)[NX], const T (&)[NU], T (&fx)[NX][NX], T (&fu)[NX][NU], bool &bad) {
-        T s, c;
-        sincos_<FAST>(x[4], s, c, bad);
+    template <class P>
+    static __device__ __forceinline__ void jac_sc(const P &p, int, const T (&x)[NX], const T (&)[NU], T (&fx)[NX][NX], T (&fu)[NX][NU], T s, T c) {
         fx[0][2] = c * p.dt;
         fx[0][4] = (-s * x[2]) * p.dt;
         fx[1][2] = s * p.dt;
@@ -207,32 +228,54 @@ template <typename T> struct CarAccModel { // systems.py:59-90
         fu[3][0] = p.dt;
         fu[4][1] = p.dt;
     }
+    template <bool FAST, class P>
+    static __device__ __forceinline__ void step(const P &p, int t, const T (&x)[NX], const T (&u)[NU], T (&xn)[NX], bool &bad) {
+        T s, c;
+        sincos_<FAST>(x[4], s, c, bad);
+        step_sc(p, t, x, u, xn, s, c);
+    }
+    template <bool FAST, class P>
+    static __device__ __forceinline__ void jac(const P &p, int t, const T (&x)[NX], const T (&u)[NU], T (&fx)[NX][NX], T (&fu)[NX][NU], bool &bad) {
+        T s, c;
+        sincos_<FAST>(x[4], s, c, bad);
+        jac_sc(p, t, x, u, fx, fu, s, c);
+    }
 };
 
 template <typename T> struct DubinsModel { // systems.py:92-121
     static constexpr int NX = 3, NU = 2;
+    static constexpr int NT = 1;
     static constexpr bool HAS_BARRIER = false;
     static constexpr bool fx_nz(int i, int j) { return i == j || (i < 2 && j == 2); }
     static constexpr bool fx_one(int i, int j) { return i == j; }
     static constexpr bool fu_nz(int i, int j) { return j == 0 || (i == 2 && j == 1); }
-    template <bool FAST, class P>
-    static __device__ __forceinline__ void step(const P &p, int, const T (&x)[NX], const T (&u)[NU], T (&xn)[NX], bool &bad) {
-        T s, c;
-        sincos_<FAST>(x[2], s, c, bad);
+    static __device__ __forceinline__ T trig_arg(const T (&x)[NX], const T (&)[NU]) { return x[2]; }
+    template <class P>
+    static __device__ __forceinline__ void step_sc(const P &p, int, const T (&x)[NX], const T (&u)[NU], T (&xn)[NX], T s, T c) {
         xn[0] = fma_(u[0] * c, p.dt, x[0]);
         xn[1] = fma_(u[0] * s, p.dt, x[1]);
         xn[2] = fma_(u[0] * u[1], p.dt, x[2]);
     }
-    template <bool FAST, class P>
-    static __device__ __forceinline__ void jac(const P &p, int, const T (&x)[NX], const T (&u)[NU], T (&fx)[NX][NX], T (&fu)[NX][NU], bool &bad) {
-        T s, c;
-        sincos_<FAST>(x[2], s, c, bad);
+    template <class P>
+    static __device__ __forceinline__ void jac_sc(const P &p, int, const T (&)[NX], const T (&u)[NU], T (&fx)[NX][NX], T (&fu)[NX][NU], T s, T c) {
         fx[0][2] = (-s * u[0]) * p.dt;
         fx[1][2] = (c * u[0]) * p.dt;
         fu[0][0] = c * p.dt;
         fu[1][0] = s * p.dt;
         fu[2][0] = u[1] * p.dt;
         fu[2][1] = u[0] * p.dt;
+    }
+    template <bool FAST, class P>
+    static __device__ __forceinline__ void step(const P &p, int t, const T (&x)[NX], const T (&u)[NU], T (&xn)[NX], bool &bad) {
+        T s, c;
+        sincos_<FAST>(x[2], s, c, bad);
+        step_sc(p, t, x, u, xn, s, c);
+    }
+    template <bool FAST, class P>
+    static __device__ __forceinline__ void jac(const P &p, int t, const T (&x)[NX], const T (&u)[NU], T (&fx)[NX][NX], T (&fu)[NX][NU], bool &bad) {
+        T s, c;
+        sincos_<FAST>(x[2], s, c, bad);
+        jac_sc(p, t, x, u, fx, fu, s, c);
     }
 };
 
@@ -274,6 +317,32 @@ template <typename T, int NX_, int NU_> struct LtvModelT {
     }
 };
 template <typename T> using Ltv12x4Model = LtvModelT<T, 12, 4>;
+
+// number of sine/cosine pairs a model shares between step() and jac(): its NT, or 0
+template <class M, class = void> struct trig_pairs { static constexpr int value = 0; };
+template <class M> struct trig_pairs<M, std::void_t<decltype(M::NT)>> { static constexpr int value = M::NT; };
+
+// One model step / Jacobian.  For a model with a shared pair (s, c): GIVEN = the caller supplies the
+// pair (read from Params::SC), else it is evaluated here and handed back.  Other models ignore it.
+template <bool FAST, bool GIVEN, class M, typename T, class P>
+__device__ __forceinline__ void model_step(const P &p, int t, const T (&x)[M::NX], const T (&u)[M::NU], T (&xn)[M::NX], T &s, T &c, bool &bad) {
+    if constexpr (trig_pairs<M>::value == 1) {
+        if (!GIVEN) sincos_<FAST>(M::trig_arg(x, u), s, c, bad);
+        M::step_sc(p, t, x, u, xn, s, c);
+    } else {
+        M::template step<FAST>(p, t, x, u, xn, bad);
+    }
+}
+template <bool FAST, bool GIVEN, class M, typename T, class P>
+__device__ __forceinline__ void model_jac(const P &p, int t, const T (&x)[M::NX], const T (&u)[M::NU], T (&fx)[M::NX][M::NX],
+                                          T (&fu)[M::NX][M::NU], T &s, T &c, bool &bad) {
+    if constexpr (trig_pairs<M>::value == 1) {
+        if (!GIVEN) sincos_<FAST>(M::trig_arg(x, u), s, c, bad);
+        M::jac_sc(p, t, x, u, fx, fu, s, c);
+    } else {
+        M::template jac<FAST>(p, t, x, u, fx, fu, bad);
+    }
+}
 
 // ---------------------------------------------------------------- cost pieces
 // e' W e with W dense row-major, as (e' W) e (ilqr.py:42), or diagonal.
@@ -477,10 +546,11 @@ __device__ __forceinline__ int solve_quu(const T (&A)[NU][NU], T (&Bm)[NU][NR], 
 // ---------------------------------------------------------------- backward
 // One Riccati step: consumes (x, u, xref) of step t and the value function of
 // step t+1, produces the gains of step t and the value function of step t.
-template <typename T, class M, bool DIAG, int CONSTR, bool FAST, class P>
+// TC: the sine/cosine pair of the step (sc_s, sc_c) comes from the cache instead of being evaluated.
+template <typename T, class M, bool DIAG, int CONSTR, bool FAST, bool TC = false, class P>
 __device__ __forceinline__ int riccati_step(const P &p, int t, const T (&x)[M::NX], const T (&u)[M::NU], const T (&xr)[M::NX],
                                             T bcx, T bcy, T brad, T (&Vx)[M::NX], T (&Vxx)[M::NX][M::NX],
-                                            T (&Kt)[M::NU][M::NX], T (&kt)[M::NU], bool &bad) {
+                                            T (&Kt)[M::NU][M::NX], T (&kt)[M::NU], bool &bad, T sc_s = T(0), T sc_c = T(0)) {
     constexpr int NX = M::NX, NU = M::NU;
     T e[NX], lx[NX], lu[NU], lxx[NX][NX];
 #pragma unroll
@@ -520,7 +590,7 @@ __device__ __forceinline__ int riccati_step(const P &p, int t, const T (&x)[M::N
 #pragma unroll
         for (int j = 0; j < NU; ++j) fu[i][j] = T(0);
     }
-    M::template jac<FAST>(p, t, x, u, fx, fu, bad);
+    model_jac<FAST, TC, M>(p, t, x, u, fx, fu, sc_s, sc_c, bad);
 
     // Qx = l_x + fx' Vx ; Qu = l_u + fu' Vx (ilqr.py:93-94)
     T Qx[NX], Qu[NU];
@@ -680,16 +750,18 @@ __device__ __forceinline__ int riccati_step(const P &p, int t, const T (&x)[M::N
 }
 
 template <typename T, int NX, int NU> struct StepRow { // the rows of one time step the backward pass reads
-    T x[NX], u[NU], xr[NX], cx, cy, rad;
+    T x[NX], u[NU], xr[NX], cx, cy, rad, s, c;
 };
 
 // One reverse sweep over the horizon for the problem of this lane; returns status bits and
 // sets `bad` if the fast trigonometry met an argument outside its range.
 // `store`: whether this lane writes its gains (only looked at when !FAST: the first, fast sweep
 // stores from every lane, see below; the redo sweep must leave the gains of the other lanes alone)
-template <typename T, class M, bool DIAG, int CONSTR, int PF, bool FAST, class P>
+// TC: sine/cosine pairs are read from SCp (Params::SC) and `store` also guards the fast sweep (the
+// lanes of converged problems may hold no valid pairs, so they must not rewrite their gains).
+template <typename T, class M, bool DIAG, int CONSTR, int PF, bool FAST, bool TC = false, class P>
 __device__ __forceinline__ int backward_sweep(const P &p, const T *Xt, const T *Rt, const T *Ut, const T *Cp, const T *Dp,
-                                              T *Kp, T *kp, bool &bad, bool store = true) {
+                                              T *Kp, T *kp, bool &bad, bool store = true, const T *SCp = nullptr) {
     constexpr int NX = M::NX, NU = M::NU;
     const int T1 = p.N - 1;
     auto load_row = [&](int t, StepRow<T, NX, NU> &r) {
@@ -706,6 +778,12 @@ __device__ __forceinline__ int backward_sweep(const P &p, const T *Xt, const T *
             r.rad = Dp[t * TILE];
         } else {
             r.cx = r.cy = r.rad = T(0);
+        }
+        if (TC) {
+            r.s = SCp[(t * 2 + 0) * TILE];
+            r.c = SCp[(t * 2 + 1) * TILE];
+        } else {
+            r.s = r.c = T(0);
         }
     };
 
@@ -748,12 +826,13 @@ __device__ __forceinline__ int backward_sweep(const P &p, const T *Xt, const T *
             StepRow<T, NX, NU> cur = ring[s];
             if (t - PF >= 0) load_row(t - PF, ring[s]);
             T Kt[NU][NX], kt[NU];
-            status |= riccati_step<T, M, DIAG, CONSTR, FAST>(p, t, cur.x, cur.u, cur.xr, cur.cx, cur.cy, cur.rad, Vx, Vxx, Kt, kt, bad);
+            status |= riccati_step<T, M, DIAG, CONSTR, FAST, TC>(p, t, cur.x, cur.u, cur.xr, cur.cx, cur.cy, cur.rad, Vx, Vxx, Kt, kt, bad,
+                                                                 cur.s, cur.c);
             // every lane stores, also those of converged problems (their trajectory has not
             // changed, so they rewrite the same bits) and the padding lanes of the last tile: a
             // branch around the stores would make the number of outstanding memory operations
             // path-dependent and force full drains of the memory queue in the loop
-            if (FAST || store) {
+            if ((FAST && !TC) || store) {
 #pragma unroll
                 for (int i = 0; i < NU; ++i) {
                     kp[(t * NU + i) * TILE] = kt[i];
@@ -766,7 +845,7 @@ __device__ __forceinline__ int backward_sweep(const P &p, const T *Xt, const T *
     return status;
 }
 
-template <typename T, class M, bool DIAG, int CONSTR, int PF>
+template <typename T, class M, bool DIAG, int CONSTR, int PF, bool TC = false>
 __global__ __launch_bounds__(64) void backward_kernel(Params<T, M::NX, M::NU> p) {
     constexpr int NX = M::NX, NU = M::NU;
     const int b0 = blockIdx.x * 64 + threadIdx.x;
@@ -788,17 +867,18 @@ __global__ __launch_bounds__(64) void backward_kernel(Params<T, M::NX, M::NU> p)
     const T *Dp = BARRIER_ ? tile_ptr(p.radius, tile, p.N, ln) : nullptr;
     T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
     T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    const T *SCp = TC ? tile_ptr(p.SC, tile, T1 * 2, ln) : nullptr;
     bool bad = false;
-    int status = backward_sweep<T, M, DIAG, CONSTR, PF, true>(p, Xt, Rt, Ut, Cp, Dp, Kp, kp, bad);
+    int status = backward_sweep<T, M, DIAG, CONSTR, PF, true, TC>(p, Xt, Rt, Ut, Cp, Dp, Kp, kp, bad, active, SCp);
     // rare: an angle outside the fast trigonometric range or a Quu that is not positive definite
     // somewhere in the wave: the lanes that raised the flag redo their sweep with the library
     // sine/cosine and the pivoted-LU fallback and replace their gains; the other lanes keep what
     // the first sweep stored, so a problem's gains do not depend on which problems share its wave.
     // (Lanes of converged problems count too: the first sweep has just overwritten their gains.)
-    const bool redo = bad && valid;
+    const bool redo = bad && valid && (!TC || active);
     if (__ballot(redo) != 0ull) {
         bool bad2 = false;
-        const int status2 = backward_sweep<T, M, DIAG, CONSTR, 1, false>(p, Xt, Rt, Ut, Cp, Dp, Kp, kp, bad2, redo);
+        const int status2 = backward_sweep<T, M, DIAG, CONSTR, 1, false, TC>(p, Xt, Rt, Ut, Cp, Dp, Kp, kp, bad2, redo, SCp);
         status = redo ? status2 : status;
     }
     if (active && status != 0 && p.status) p.status[o] |= status;
@@ -1103,7 +1183,7 @@ __device__ __forceinline__ void control_update(const P &p, T alpha, const T (&x)
 }
 
 template <typename T, int NX, int NU> struct FwdRow { // rows of one step shared by all step sizes of a problem
-    T K[NU][NX], k[NU], xp[NX], up[NU], xr[NX], cx, cy, rad;
+    T K[NU][NX], k[NU], xp[NX], up[NU], xr[NX], cx, cy, rad, s, c;
 };
 
 // One time step of one line-search candidate: stage cost of (x, u_new) and the next state
@@ -1151,10 +1231,12 @@ __device__ __forceinline__ T candidate_total(const P &p, const T (&x)[M::NX], co
 // line search has committed a step, see commit_kernel), so the previous states the feedback
 // term needs are rolled out again in registers instead of being read: one more model step per
 // time step, NX fewer values of traffic.
-template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool REROLL, bool FAST, class P>
+// TC (with REROLL): the previous trajectory's sine/cosine pairs come from SCp (Params::SC), which
+// turns its re-rollout into a few multiply-adds.
+template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool REROLL, bool FAST, bool TC = false, class P>
 __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T *Rt, const T *Ut, const T *Kp, const T *kp,
                                                 const T *Cp, const T *Dp, int al, bool active, T Jcur, int base0, int end,
-                                                int &best, T &best_cost, bool &bad) {
+                                                int &best, T &best_cost, bool &bad, const T *SCp = nullptr) {
     constexpr int NX = M::NX, NU = M::NU;
     const int T1 = p.N - 1;
     auto load_row = [&](int t, FwdRow<T, NX, NU> &r) {
@@ -1176,6 +1258,12 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
             r.rad = Dp[t * TILE];
         } else {
             r.cx = r.cy = r.rad = T(0);
+        }
+        if (REROLL && TC) {
+            r.s = SCp[(t * 2 + 0) * TILE];
+            r.c = SCp[(t * 2 + 1) * TILE];
+        } else {
+            r.s = r.c = T(0);
         }
     };
     best = 0x7fffffff;
@@ -1205,7 +1293,7 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
             for (int j = 0; j < A; ++j) candidate_step<T, M, DIAG, BARRIER, FAST>(p, t, alpha[j], r, x[j], cost[j], bad);
             if (REROLL) {
                 T xqn[NX];
-                M::template step<FAST>(p, t, xq, r.up, xqn, bad);
+                model_step<FAST, TC, M>(p, t, xq, r.up, xqn, r.s, r.c, bad);
 #pragma unroll
                 for (int i = 0; i < NX; ++i) xq[i] = xqn[i];
             }
@@ -1254,7 +1342,7 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
 // them while candidates remain is appended to a device-side list; stage two
 // (evaluate_listed_kernel) walks that list with the remaining candidates.  Candidates are still
 // examined in increasing index order, so the result is that of the serial search.
-template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool REROLL>
+template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool REROLL, bool TC = false>
 __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T, M::NX, M::NU> p, int end) {
     constexpr int NX = M::NX, NU = M::NU;
     constexpr int PPW = 64 / L; // problems per wave
@@ -1285,7 +1373,9 @@ __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T,
     int best;
     T best_cost;
     bool bad = false;
-    evaluate_rounds<T, M, DIAG, BARRIER, L, A, REROLL, true>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, 0, end, best, best_cost, bad);
+    const T *SCp = (REROLL && TC) ? tile_ptr(p.SC, tile, T1 * 2, ln) : nullptr;
+    evaluate_rounds<T, M, DIAG, BARRIER, L, A, REROLL, true, TC>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, 0, end, best, best_cost, bad,
+                                                                  SCp);
     // an angle outside the fast trigonometric range anywhere in the wave: redo with the library
     // routine; a problem one of whose lanes saw such an angle takes the redone result (and tells
     // the commit kernel to use the library routine too), the others keep theirs, so a problem's
@@ -1297,7 +1387,8 @@ __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T,
         int best2;
         T best_cost2;
         bool bad2 = false;
-        evaluate_rounds<T, M, DIAG, BARRIER, L, A, REROLL, false>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, 0, end, best2, best_cost2, bad2);
+        evaluate_rounds<T, M, DIAG, BARRIER, L, A, REROLL, false, TC>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, 0, end, best2, best_cost2,
+                                                                       bad2, SCp);
         best = pbad ? best2 : best;
         best_cost = pbad ? best_cost2 : best_cost;
     }
@@ -1865,13 +1956,16 @@ static __global__ __launch_bounds__(1024) void ltv12x4_evaluate_mfma_f32_kernel(
 // stores go to a scratch slot `trash` (still no branch around the stores).
 // `mute`: this lane belongs to the other sweep of the kernel (fast / library trigonometry): all
 // its stores go to the scratch slot.
-template <typename T, class M, int PF, bool REROLL, bool FAST, class P>
+// TC: the sine/cosine pair of every step of the trajectory being written goes to SCt (Params::SC),
+// and with REROLL the old trajectory's pairs are read from there first.
+// PF: rows of the next PF time steps are in flight while a step is computed.
+template <typename T, class M, int PF, bool REROLL, bool FAST, bool TC = false, class P>
 __device__ __forceinline__ void commit_sweep(const P &p, T *Xt, T *Ut, const T *Kp, const T *kp, T *trash, T alpha, bool roll,
-                                             bool keep_ok, bool pend, bool mute) {
+                                             bool keep_ok, bool pend, bool mute, T *SCt = nullptr) {
     constexpr int NX = M::NX, NU = M::NU;
     const int T1 = p.N - 1;
     struct Row {
-        T K[NU][NX], k[NU], xp[NX], up[NU];
+        T K[NU][NX], k[NU], xp[NX], up[NU], s, c;
     };
     auto load_row = [&](int t, Row &r) {
 #pragma unroll
@@ -1885,63 +1979,85 @@ __device__ __forceinline__ void commit_sweep(const P &p, T *Xt, T *Ut, const T *
 #pragma unroll
             for (int i = 0; i < NX; ++i) r.xp[i] = Xt[(t * NX + i) * TILE];
         }
+        if (REROLL && TC) {
+            r.s = SCt[(t * 2 + 0) * TILE];
+            r.c = SCt[(t * 2 + 1) * TILE];
+        } else {
+            r.s = r.c = T(0);
+        }
     };
     T x[NX], xq[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) xq[i] = x[i] = Xt[i * TILE];
-    Row nxt;
-    load_row(0, nxt);
+    // every row is read before any store reaches it: the ring holds rows t .. t+PF-1 while step t
+    // writes rows t (inputs, pairs) and t+1 (states, which nothing but the !REROLL ring reads, ahead of the store)
+    Row ring[PF];
+#pragma unroll
+    for (int s = 0; s < PF; ++s)
+        if (s < T1) load_row(s, ring[s]);
     T xlast[NX]; // previous states of the terminal step, needed to keep lanes without a winner unchanged
     if (!REROLL) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) xlast[i] = Xt[(T1 * NX + i) * TILE];
     }
     bool bad = false, badq = false;
-    for (int t = 0; t < T1; ++t) {
-        Row r = nxt;
-        // the row of step t+1 is read here, before the store to it below
-        if (t + 1 < T1) load_row(t + 1, nxt);
-        if (REROLL) {
+    for (int tb = 0; tb < T1; tb += PF) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) r.xp[i] = xq[i];
-        }
-        T un[NU], xn[NX];
-        control_update<T, M>(p, alpha, x, r.xp, r.up, r.K, r.k, un);
-        M::template step<FAST>(p, t, x, un, xn, bad);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) x[i] = xn[i];
-        if (REROLL) {
-            T xqn[NX];
-            M::template step<FAST>(p, t, xq, r.up, xqn, badq);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) xq[i] = xqn[i];
-        }
-        // Every lane stores; a lane whose problem has no accepted step writes back the values it
-        // read (no branch around the stores: see backward_sweep)
-        // `pend`: the problem is being decided and committed by the second line-search stage,
-        // which may run beside this kernel: nothing of it may be written here
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            T *dst = (pend || mute) ? trash : &Ut[(t * NU + i) * TILE];
-            *dst = roll ? un[i] : r.up[i];
-        }
-        // the recomputed old states are the stored ones only while the fast trigonometry was in
-        // range (the library routine may differ from it in the last bit)
-        const bool real = !mute && (roll || (!pend && FAST && keep_ok && !badq));
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
+        for (int sl = 0; sl < PF; ++sl) {
+            const int t = tb + sl;
+            if (t >= T1) break;
+            Row r = ring[sl];
+            if (t + PF < T1) load_row(t + PF, ring[sl]);
+            const Row &nxt = ring[(sl + 1) % PF]; // row t+1 (if there is one)
             if (REROLL) {
-                T *dst = real ? &Xt[((t + 1) * NX + i) * TILE] : trash;
-                *dst = roll ? xn[i] : xq[i];
-            } else {
-                T *dst = (pend || mute) ? trash : &Xt[((t + 1) * NX + i) * TILE];
-                *dst = roll ? xn[i] : (t + 1 < T1 ? nxt.xp[i] : xlast[i]);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) r.xp[i] = xq[i];
+            }
+            T un[NU], xn[NX], sn = T(0), cn = T(0);
+            control_update<T, M>(p, alpha, x, r.xp, r.up, r.K, r.k, un);
+            model_step<FAST, false, M>(p, t, x, un, xn, sn, cn, bad);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = xn[i];
+            if (REROLL) {
+                T xqn[NX];
+                model_step<FAST, TC, M>(p, t, xq, r.up, xqn, r.s, r.c, badq);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xq[i] = xqn[i];
+            }
+            // Every lane stores; a lane whose problem has no accepted step writes back the values it
+            // read (no branch around the stores: see backward_sweep)
+            // `pend`: the problem is being decided and committed by the second line-search stage,
+            // which may run beside this kernel: nothing of it may be written here
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                T *dst = (pend || mute) ? trash : &Ut[(t * NU + i) * TILE];
+                *dst = roll ? un[i] : r.up[i];
+            }
+            if (TC) {
+                // without old pairs at hand (!REROLL) only the lanes that roll have something to store
+                T *ds = (pend || mute || (!REROLL && !roll)) ? trash : &SCt[(t * 2 + 0) * TILE];
+                T *dc = (pend || mute || (!REROLL && !roll)) ? trash : &SCt[(t * 2 + 1) * TILE];
+                *ds = (roll || !REROLL) ? sn : r.s;
+                *dc = (roll || !REROLL) ? cn : r.c;
+            }
+            // the recomputed old states are the stored ones only while the fast trigonometry was in
+            // range (the library routine may differ from it in the last bit)
+            const bool real = !mute && (roll || (!pend && FAST && keep_ok && !badq));
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                if (REROLL) {
+                    T *dst = real ? &Xt[((t + 1) * NX + i) * TILE] : trash;
+                    *dst = roll ? xn[i] : xq[i];
+                } else {
+                    T *dst = (pend || mute) ? trash : &Xt[((t + 1) * NX + i) * TILE];
+                    *dst = roll ? xn[i] : (t + 1 < T1 ? nxt.xp[i] : xlast[i]);
+                }
             }
         }
     }
 }
 
-template <typename T, class M, int PF, bool REROLL>
+template <typename T, class M, int PF, bool REROLL, bool TC = false>
 __global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, int it) {
     constexpr int NX = M::NX, NU = M::NU;
     const int b0 = blockIdx.x * 64 + threadIdx.x;
@@ -1997,9 +2113,10 @@ __global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, i
     // library routine is made up front and per problem, from what the evaluate kernel saw on it:
     // the fast sweep writes nothing for a problem that needs the library routine, and the second
     // sweep (rare) writes only those, so a problem's result does not depend on its wave-mates.
-    commit_sweep<T, M, PF, REROLL, true>(p, Xt, Ut, Kp, kp, trash, alpha, roll && !slow, keep_ok, pend, slow);
+    T *SCt = TC ? tile_ptr(p.SC, tile, T1 * 2, ln) : nullptr;
+    commit_sweep<T, M, PF, REROLL, true, TC>(p, Xt, Ut, Kp, kp, trash, alpha, roll && !slow, keep_ok, pend, slow, SCt);
     if (__ballot(slow) != 0ull)
-        commit_sweep<T, M, 1, REROLL, false>(p, Xt, Ut, Kp, kp, trash, alpha, slow, keep_ok, pend, !slow);
+        commit_sweep<T, M, 1, REROLL, false, TC>(p, Xt, Ut, Kp, kp, trash, alpha, slow, keep_ok, pend, !slow, SCt);
 }
 
 // ---------------------------------------------------------------- active-set compaction

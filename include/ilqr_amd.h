@@ -99,7 +99,12 @@ typedef struct ilqr_desc {
                                   launches it; ilqr_forward_evaluate_stage 1 does nothing); <= 0 (default): it
                                   runs before the commit, on the caller's stream.  Same results either way;
                                   slower on MI355X at B = 65536 (the two kernels fight over memory). */
-    int32_t reserved2;
+    int32_t trig_cache;        /* > 0: the commits keep sine and cosine of the heading of every step of the committed
+                                  trajectory in `work` (16 bytes per step and problem) and the backward pass and the
+                                  line search read them instead of evaluating them again (same bits; a third fewer
+                                  instructions per iteration, more traffic); 0 = auto (on up to 16384 problems, where
+                                  the passes are bound by their instruction stream); < 0: off.  Built-in models without
+                                  compaction only; ignored otherwise. */
     double dt;               /* system.dt (systems.py:30); the solver's own dt argument is unused (ilqr.py:20) */
     double lm_parameter;     /* ilqr.py:30, added to Vxx (ilqr.py:95) */
     double alpha_floor;      /* 1e-4 (ilqr.py:71) or alpha_terminal (cilqr.py:41) */

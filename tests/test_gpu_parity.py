@@ -835,3 +835,163 @@ def test_subclass_with_own_dynamics_is_not_solved_with_the_builtin_kernels(ilqr_
     o.inputs, o.states, o.converge = p["init_inputs"].copy(), p["init_states"].copy(), np.zeros(3, dtype=bool)
     o()                                               # the SAME solver object notices the change too
     assert np.array_equal(o.min_cost, o2.min_cost)
+
+
+def test_sine_cosine_cache_does_not_change_a_bit(ilqr_cls):
+    """For small batches the commits keep the sine/cosine of the heading of every step in memory and
+    the backward pass and the line search read them instead of evaluating them again: every output
+    must equal the run without the cache, bit for bit (all three shipped models, fp64 and fp32,
+    including a problem that starts at its optimum with states that are not a rollout, one whose
+    heading is outside the fast routine's range, and the phase-call route)."""
+    from ilqr_amd import problems, systems
+    p = problems.car_batch(150, 110)
+    p["init_states"][0] = p["target_states"][0]
+    p["init_inputs"][0] = 0.0
+    p["init_states"][7, :, 3] += 3.0e6
+    p["target_states"][7, :, 3] += 3.0e6
+    for dtype in (np.float64, np.float32):
+        ref = _solve_batch(ilqr_cls, p, trig_cache=-1, dtype=dtype)
+        Kr, kr = ref.K.copy(), ref.k.copy()
+        assert (ref.iterations > 3).any() and ref.converge[0]
+        for kw in (dict(), dict(lanes_per_problem=16, alphas_per_lane=1), dict(lanes_per_problem=4, alphas_per_lane=4),
+                   dict(lanes_per_problem=1, alphas_per_lane=6), dict(lanes_per_problem=8, alphas_per_lane=2, n_streams=2)):
+            o = _solve_batch(ilqr_cls, p, trig_cache=1, dtype=dtype, **kw)
+            for key in ("states", "inputs", "min_cost", "iterations", "converge", "status"):
+                assert np.array_equal(getattr(o, key), getattr(ref, key), equal_nan=True), (dtype, kw, key)
+            assert np.array_equal(o.alpha_history, ref.alpha_history)
+            assert np.array_equal(o.cost_history, ref.cost_history, equal_nan=True)
+            active_end = ~ref.converge          # gains of converged problems are those of their last pass either way
+            assert np.array_equal(o.K, Kr) and np.array_equal(o.k, kr), (dtype, kw, active_end.sum())
+    # the other two shipped models
+    for gen, cls, Q, R, lim in ((problems.caracc_batch, systems.CarAcceleration, problems.CARACC_Q, problems.CARACC_R, problems.CARACC_LIMITS),
+                                (problems.dubins_batch, systems.DubinsCar, problems.DUBINS_Q, problems.DUBINS_R, problems.DUBINS_LIMITS)):
+        q = gen(70, 80)
+        outs = []
+        for tc in (-1, 1):
+            s = cls()
+            s.set_cost(Q.copy(), R.copy())
+            s.set_control_limit(*lim)
+            o = ilqr_cls(s, q["target_states"], s.dt, history=True, trig_cache=tc)
+            o.inputs, o.states = q["init_inputs"].copy(), q["init_states"].copy()
+            o()
+            outs.append(o)
+        for key in ("states", "inputs", "min_cost", "iterations", "converge", "K", "k"):
+            assert np.array_equal(getattr(outs[0], key), getattr(outs[1], key)), (cls.__name__, key)
+    # phase calls: the handle switches to the cached pairs after the first commit
+    car = demo_car_system()
+    outs = []
+    for tc in (-1, 1):
+        o = ilqr_cls(car, p["target_states"], car.dt, history=True, trig_cache=tc)
+        o.inputs, o.states = p["init_inputs"].copy(), p["init_states"].copy()
+        dev = o.upload()
+        dev.initial_cost()
+        for it in range(7):
+            dev.backward()
+            dev.forward(it)
+        o.download()
+        outs.append((o.states.copy(), o.inputs.copy(), o.min_cost.copy(), o.K.copy(), o.k.copy()))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
+# --------------------------------------------------------------------------- full size, the other configurations
+def test_full_size_constrained_batch_properties(oracle):
+    """cilqr (box QP in the backward pass + relaxed log barrier on bubbles and the speed box) at
+    B = 16384, N = 200, maxIter = 100: size-independent properties for every problem and a sampled
+    per-iteration comparison with the oracle."""
+    from ilqr_amd import problems
+    from ilqr_amd.cilqr import iterative_LQR as CILQR
+    from ilqr_amd.constraints import BubbleConstraint
+    B, N = 16384, 200
+    p = problems.car_batch(B, N, noise_xy=15.0)
+    centers, radius, vb = problems.bubbles_for(p["target_states"], radius=6.0, vel_bounds=(-1.0, 14.0))
+    car = demo_car_system()
+    car.Q_f = car.Q * 2
+    con = BubbleConstraint(N)
+    con.setup(centers, radius, vb)
+    opt = CILQR(car, p["target_states"], car.dt, history=True)
+    opt.inputs, opt.states = p["init_inputs"].copy(), p["init_states"].copy()
+    opt.set_barrier(con, mu=50.0, delta=0.5)
+    opt()
+    assert np.all(opt.status == 0) and np.all(np.isfinite(opt.min_cost))
+    assert np.all(opt.iterations >= 1) and np.all(opt.converge | (opt.iterations == 100))
+    hc, ha = opt.cost_history, opt.alpha_history
+    assert set(np.unique(ha)) <= set(range(-2, 8))                       # 8 step sizes (alpha_terminal 1e-2)
+    for it in range(1, 100):
+        acc = (opt.iterations > it) & (ha[:, it] >= 0)
+        assert np.all(hc[acc, it] < hc[acc, it - 1])
+    lo, hi = np.array(car.control_lower_limit), np.array(car.control_upper_limit)
+    moved = (ha >= 0).any(axis=1)      # a problem whose first search fails keeps its (unclamped) initial inputs
+    assert moved.mean() > 0.5
+    assert np.all(opt.inputs[moved] >= lo - 1e-15) and np.all(opt.inputs[moved] <= hi + 1e-15)
+    assert np.array_equal(opt.inputs[~moved], p["init_inputs"][~moved])
+    d = oracle.make_desc(car, N, max_iter=100, alpha_floor=1e-2, solver_control_limited=True, barrier=True, mu=50.0,
+                         delta=0.5, vel_bounds=vb)
+    sel = np.flatnonzero(moved)[5::683]
+    for b in sel:
+        roll = [opt.states[b, 0]]
+        for t in range(N - 1):
+            roll.append(car.model_f(roll[-1], opt.inputs[b, t]))
+        assert nrm(np.array(roll), opt.states[b]) <= 1e-12
+        c = oracle.cost(d, np.ascontiguousarray(p["target_states"][b]), np.ascontiguousarray(opt.states[b]),
+                        np.ascontiguousarray(opt.inputs[b]), centers=np.ascontiguousarray(centers[b]),
+                        radius=np.ascontiguousarray(radius[b]))
+        assert abs(c - opt.min_cost[b]) <= 1e-12 * abs(c)
+    for b in sel[:16]:
+        st, ui = p["init_states"][b].copy(), p["init_inputs"][b].copy()
+        r = oracle.solve(d, np.ascontiguousarray(p["target_states"][b]), st, ui, centers=np.ascontiguousarray(centers[b]),
+                         radius=np.ascontiguousarray(radius[b]), history=False)
+        n = min(int(opt.iterations[b]), r["iters"])
+        assert n >= r["iters"] - 3
+        rel = np.abs(hc[b, :n] - r["hist_cost"][:n]) / np.abs(r["hist_cost"][:n])
+        assert rel.max() <= 1e-9
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_full_size_ltv_batch(ilqr_cls, oracle, dtype):
+    """The n = 12, m = 4 table-driven configuration at its full size (B = 32768, N = 500) on the
+    matrix-unit kernels: problem 1 of the batch is the problem of the reference-generated fixture
+    ltv12x4_N500_seed1, further problems are compared with the oracle, and for all problems the
+    accepted costs fall."""
+    from ilqr_amd import problems
+    g = load_golden("ltv12x4_N500_seed1")
+    B, N = 32768, 500
+    s = ltv_setup(N)
+    p = problems.ltv_batch(B, N)
+    assert np.array_equal(p["target_states"][1], g["target_states"]) and np.array_equal(p["x0"][1], g["x0"])
+    opt = ilqr_cls(s, p["target_states"], s.dt, history=True, dtype=dtype)
+    opt.inputs, opt.states = p["init_inputs"], p["init_states"]
+    dev = opt.upload()
+    opt.solve_device()
+    J = dev.J.cpu().numpy().astype(np.float64)
+    iters = dev.iters.cpu().numpy()
+    conv = dev.converged.cpu().numpy()
+    stat = dev.status.cpu().numpy()
+    hc = dev.hist_cost.cpu().numpy().T.astype(np.float64)
+    ha = dev.hist_alpha.cpu().numpy().T
+    assert np.all(stat == 0) and np.all(np.isfinite(J)) and np.all(iters >= 1)
+    assert np.all((conv != 0) | (iters == 30))
+    for it in range(1, 30):
+        acc = (iters > it) & (ha[:, it] >= 0)
+        assert np.all(hc[acc, it] < hc[acc, it - 1])
+    it_ref = int(g["iters"])
+    if dtype == np.float64:
+        solid = noise_floor_mask(g["hist_cost"][:it_ref], float(g["cost0"]))
+        last_solid = int(np.nonzero(solid)[0].max()) + 1
+        n = min(int(iters[1]), it_ref)
+        assert n >= last_solid
+        assert (np.abs(hc[1, :n] - g["hist_cost"][:n]) / g["hist_cost"][:n]).max() <= 1e-9
+        assert np.array_equal(ha[1, :n][solid[:n]], g["hist_alpha"][:n][solid[:n]])
+        assert abs(J[1] - float(g["min_cost"])) <= 1e-9 * float(g["min_cost"])
+        d = oracle.make_desc(s, N)
+        for b in (0, 777, 32767):
+            r = oracle.solve(d, np.ascontiguousarray(p["target_states"][b]), p["init_states"][b].copy(), p["init_inputs"][b].copy(),
+                             history=False)
+            so = noise_floor_mask(r["hist_cost"], r["cost0"])
+            ls = int(np.nonzero(so)[0].max()) + 1 if so.any() else 0
+            n = min(int(iters[b]), r["iters"])
+            assert n >= ls and n >= 1
+            assert (np.abs(hc[b, :n] - r["hist_cost"][:n]) / r["hist_cost"][:n]).max() <= 1e-9
+    else:   # fp32 mode has its own bounds
+        assert abs(hc[1, 0] - g["hist_cost"][0]) <= 1e-4 * g["hist_cost"][0]
+        assert abs(J[1] - float(g["min_cost"])) <= 2e-3 * float(g["min_cost"])
