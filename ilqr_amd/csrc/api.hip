@@ -33,6 +33,7 @@ struct ilqr_handle {
     int n_parts = 1;
     int repack_every = 0;   // 0: no compaction
     bool trig = false;      // sine/cosine cache in `work` (HostCtx::trig)
+    bool seg = false;       // candidate checkpoints in `work`, time-parallel commit (HostCtx::seg)
     // the phase calls (ilqr_backward ...) and the single-stream ilqr_solve work on the whole batch as
     // one part whose compaction state lives here, between calls
     PartState whole;
@@ -351,6 +352,12 @@ int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
     h->trig = ops->trig_pairs == 1 && h->repack_every == 0 && d.recompute_states >= 0 && d.overlap_stages <= 0 &&
               (d.trig_cache > 0 || (d.trig_cache == 0 && d.B <= 16384));
     h->ctx.trig = h->trig;
+    // Time-parallel commit: 0 = auto, for the same batch sizes (one lane per problem leaves most of the
+    // chip idle during the sequential commit); needs a single-stage line search with four or more
+    // lanes per problem (the launch tables check that), no compaction, one part.
+    h->seg = d.n <= 8 && h->repack_every == 0 && d.overlap_stages <= 0 && h->n_parts == 1 && L >= 4 && L * A >= na && na <= 16 &&
+             (d.segment_commit > 0 || (d.segment_commit == 0 && d.B <= 8192)); // (16384: 14.6 against 14.5 ms, no gain)
+    h->ctx.seg = h->seg;
     // off unless asked for: beside the bandwidth-bound commit the latency-bound second stage runs
     // 2.5x slower and slows the commit down (measured: 34.8 -> 42.0 ms per solve at B = 65536)
     h->overlap = d.overlap_stages > 0 && h->n_parts == 1;
@@ -374,7 +381,7 @@ void ilqr_destroy(ilqr_handle *h) {
 }
 
 // layout of `work`: see work_layout() in host.hpp
-size_t ilqr_workspace_bytes(const ilqr_handle *h) { return h ? work_layout(h->ctx.d, h->repack_every > 0, h->trig).total : 0; }
+size_t ilqr_workspace_bytes(const ilqr_handle *h) { return h ? work_layout(h->ctx.d, h->repack_every > 0, h->trig, h->seg).total : 0; }
 
 int32_t ilqr_num_alphas(const ilqr_handle *h) { return h ? h->ctx.n_alphas : 0; }
 
@@ -439,6 +446,7 @@ static HostCtx &phase_ctx(ilqr_handle *h) {
     h->whole.ctx.reroll = h->ctx.reroll;
     h->whole.ctx.select_converged = false;
     h->whole.ctx.trig = h->trig;
+    h->whole.ctx.seg = h->seg;
     h->whole.ctx.eval_stages = 3;
     h->whole.ctx.side = h->ctx.side;
     h->whole.ctx.ev_fork = h->ctx.ev_fork;
@@ -512,7 +520,9 @@ int ilqr_forward(ilqr_handle *h, int32_t iteration, void *stream) {
 
 // The iteration driver behind ilqr_solve and ilqr_solve_static.  `work`: the scratch buffer the
 // kernels use for this call (the bound one, or the library's own static array).
-static int solve_impl(ilqr_handle *h, int32_t max_iter, void *work, bool compaction, bool trig, void *stream) {
+// `extras`: `work` has room for what the handle's workspace holds beyond the scratch proper
+// (sine/cosine cache, candidate checkpoints).
+static int solve_impl(ilqr_handle *h, int32_t max_iter, void *work, bool compaction, bool extras, void *stream) {
     if (hipError_t e0 = ensure_side(h); e0 != hipSuccess) return hip_rc(e0);
     hipStream_t user = (hipStream_t)stream;
     const int np = h->n_parts;
@@ -542,7 +552,8 @@ static int solve_impl(ilqr_handle *h, int32_t max_iter, void *work, bool compact
     for (int s = 0; s < np && rc == ILQR_OK; ++s) {
         part[s].ctx = h->ctx;
         part[s].ctx.b.work = work;
-        part[s].ctx.trig = trig;
+        part[s].ctx.trig = extras && h->trig;
+        part[s].ctx.seg = extras && h->seg;
         part[s].index = s;
         const int t0 = (int)((long)tiles * s / np), t1 = (int)((long)tiles * (s + 1) / np);
         part[s].ctx.first = t0 * TILE;
@@ -594,7 +605,7 @@ int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream) {
     if (max_iter < 0) return ILQR_ERR_INVALID;
     REQUIRE_UNPACKED(h);
     if (!h->ctx.b.work) return ILQR_ERR_NOT_BOUND;
-    return solve_impl(h, max_iter, h->ctx.b.work, true, h->trig, stream);
+    return solve_impl(h, max_iter, h->ctx.b.work, true, true, stream);
 }
 
 int ilqr_solve_static(ilqr_handle *h, int32_t max_iter, void *stream) {
@@ -624,7 +635,7 @@ int ilqr_solve_static(ilqr_handle *h, int32_t max_iter, void *stream) {
     // the array keeps what the last call left in it: start from zeros
     e = hipMemsetAsync(ptr, 0, need, (hipStream_t)stream);
     if (e != hipSuccess) return hip_rc(e);
-    return solve_impl(h, max_iter, ptr, false, false, stream); // the static array has no room for the sine/cosine cache
+    return solve_impl(h, max_iter, ptr, false, false, stream); // the static array holds neither cache nor checkpoints
 }
 
 int ilqr_rollout(ilqr_handle *h, void *stream) {

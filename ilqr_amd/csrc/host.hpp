@@ -28,6 +28,9 @@ struct HostCtx {
     // the commits keep the sine/cosine pairs of the committed trajectory in `work` (Params::SC) and,
     // while `reroll` holds, the backward pass and the line search read them instead of evaluating
     bool trig = false;
+    // time-parallel commit: the (single-stage) line search keeps candidate checkpoints in `work`
+    // (Params::CK) and the commit rolls all segments out at once (commit_segments_kernel)
+    bool seg = false;
     int eval_stages = 3;           // line search: bit 0 = stage one, bit 1 = stage two (see evaluate_kernel)
     // stage two fused with the commit of its problems, beside the commit of the others: the stream
     // and events it runs on (null: stage two runs before the commit, on the caller's stream)
@@ -51,10 +54,13 @@ struct WorkLayout {
     size_t set[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}; // X, U, Xref, centers, radius of the two working sets
     size_t Kw = 0, kw = 0;
     size_t sc = 0; // sine/cosine cache (only with `trig`; never together with compaction)
+    size_t ck = 0; // candidate checkpoints (only with `seg`; never together with compaction)
     size_t total = 0;
 };
 
-static inline WorkLayout work_layout(const ilqr_desc &d, bool compaction, bool trig = false) {
+static inline int commit_segments(const ilqr_desc &d) { return (d.N - 1 + COMMIT_SEG - 1) / COMMIT_SEG; }
+
+static inline WorkLayout work_layout(const ilqr_desc &d, bool compaction, bool trig = false, bool seg = false) {
     WorkLayout w;
     const size_t e = d.dtype == ILQR_F64 ? 8 : 4;
     const size_t tiles = ((size_t)d.B + TILE - 1) / TILE, Bp = tiles * TILE;
@@ -89,8 +95,10 @@ static inline WorkLayout work_layout(const ilqr_desc &d, bool compaction, bool t
         }
         w.Kw = take(Bp * T1 * m * n * e);
         w.kw = take(Bp * T1 * m * e);
-    } else if (trig) {
-        w.sc = take(Bp * (size_t)(d.N - 1) * 2 * e);
+    } else {
+        // (the cache comes first: its offset does not depend on `seg`)
+        if (trig) w.sc = take(Bp * (size_t)(d.N - 1) * 2 * e);
+        if (seg) w.ck = take(Bp * (size_t)commit_segments(d) * CK_CANDIDATES * d.n * e);
     }
     w.total = off;
     return w;
@@ -169,6 +177,9 @@ template <typename T, int NX, int NU> static Params<T, NX, NU> make_params(const
     p.list_count = (int32_t *)((char *)b.work + wl.list_count) + tile0;
     p.trash = (T *)((char *)b.work + wl.trash) + c.first;
     p.SC = (c.trig && !packed) ? (T *)((char *)b.work + work_layout(d, false, true).sc) + tile0 * (size_t)(T1 * 2) * TILE : nullptr;
+    p.CK = (c.seg && !packed) ? (T *)((char *)b.work + work_layout(d, false, c.trig, true).ck) +
+                                    tile0 * (size_t)commit_segments(d) * CK_CANDIDATES * NX * TILE
+                              : nullptr;
     p.redo = flat((int32_t *)((char *)b.work + wl.redo));
     p.J = flat((T *)b.J);
     p.Jtry = flat((T *)((char *)b.work + wl.jtry));
@@ -250,6 +261,12 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
     static constexpr bool HAS_TRIG = trig_pairs<M>::value == 1;
     // the cached pairs are valid exactly when the previous states may be rolled out again
     static bool use_trig(const HostCtx &c) { return HAS_TRIG && c.trig && c.reroll && c.ws.slot2orig == nullptr && !c.select_converged; }
+    // the time-parallel commit needs every candidate in one round and four or more lanes per problem
+    // (the mappings built with checkpoints), the plain buffers and the whole batch in one launch
+    static bool use_seg(const HostCtx &c) {
+        return M::NX <= 8 && c.seg && c.L >= 4 && c.L * c.A >= c.n_alphas && c.n_alphas <= CK_CANDIDATES && c.ws.slot2orig == nullptr &&
+               c.side == nullptr;
+    }
     template <int CONSTR> static hipError_t backward_c(const HostCtx &c, hipStream_t s) {
         auto p = make_params<T, NX, NU>(c);
         if constexpr (HAS_TRIG) {
@@ -302,8 +319,23 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
         // problem).  Not with one step size per lane: there the evaluation of the pair is what covers
         // the latency of the next row's loads, and the kernel is faster with it (measured: 9.24
         // against 9.47 ms per solve of 4096 problems; with two or four step sizes per lane the cache wins)
-        if constexpr (HAS_TRIG && REROLL && L >= 4 && A >= 2) {
-            if (use_trig(c)) {
+        constexpr bool TC_BUILT = HAS_TRIG && REROLL && L >= 4 && A >= 2;
+        const bool tc = TC_BUILT && use_trig(c);
+        // with candidate checkpoints for the time-parallel commit: single-stage mappings of small batches
+        if constexpr (M::NX <= 8 && L >= 4) {
+            if (use_seg(c)) {
+                if constexpr (TC_BUILT) {
+                    if (tc) {
+                        hipLaunchKernelGGL((evaluate_kernel<T, M, DIAG, BARRIER, L, A, REROLL, true, true>), dim3(blocks), dim3(256), 0, s, p, first_end);
+                        return hipGetLastError();
+                    }
+                }
+                hipLaunchKernelGGL((evaluate_kernel<T, M, DIAG, BARRIER, L, A, REROLL, false, true>), dim3(blocks), dim3(256), 0, s, p, first_end);
+                return hipGetLastError();
+            }
+        }
+        if constexpr (TC_BUILT) {
+            if (tc) {
                 hipLaunchKernelGGL((evaluate_kernel<T, M, DIAG, BARRIER, L, A, REROLL, true>), dim3(blocks), dim3(256), 0, s, p, first_end);
                 return hipGetLastError();
             }
@@ -414,6 +446,17 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
     }
     template <bool REROLL> static hipError_t commit_r(const HostCtx &c, int it, hipStream_t s) {
         auto p = make_params<T, NX, NU>(c);
+        if constexpr (M::NX <= 8) {
+            if (use_seg(c)) {
+                const int nseg = commit_segments(c.d);
+                const dim3 grid(((c.count + 63) / 64) * nseg);
+                if (HAS_TRIG && c.trig)
+                    hipLaunchKernelGGL((commit_segments_kernel<T, M, HAS_TRIG>), grid, dim3(64), 0, s, p, it, nseg);
+                else
+                    hipLaunchKernelGGL((commit_segments_kernel<T, M, false>), grid, dim3(64), 0, s, p, it, nseg);
+                return hipGetLastError();
+            }
+        }
         if constexpr (HAS_TRIG) {
             // every commit of a handle with the cache keeps it up to date, whether or not it can read it yet
             if (c.trig && c.ws.slot2orig == nullptr) {

@@ -102,6 +102,17 @@ constexpr int TILE = 64;
 #define EVAL_MIN_WAVES 1
 #endif
 
+// Time-parallel commit (small batches): the line search keeps the state of every candidate at the
+// start of every segment of COMMIT_SEG time steps (Params::CK), so the accepted candidate can be
+// rolled out again segment by segment, all segments at once (commit_segments_kernel).  Measured at
+// N = 200: 8 / 16 / 32 steps per segment -> 7.6 / 7.4 / 7.2 ms per solve of 4096 problems and
+// 10.7 / 9.95 / 9.7 ms of 8192 (the checkpoints are write traffic of the line search; the commit
+// itself runs at memory speed from 8 steps per segment on).
+#ifndef ILQR_COMMIT_SEG
+#define ILQR_COMMIT_SEG 32
+#endif
+constexpr int COMMIT_SEG = ILQR_COMMIT_SEG;
+constexpr int CK_CANDIDATES = 16; // candidate slots per segment start
 template <typename T> __device__ __forceinline__ T *tile_ptr(T *base, int tile, int rows, int lane) {
     return base + (size_t)tile * (size_t)rows * TILE + lane;
 }
@@ -139,6 +150,10 @@ template <typename T, int NX, int NU> struct Params {
     // a third of all instructions of a Car iteration.  Costs 16 bytes of traffic per step and pass,
     // so it pays where the passes are bound by their instruction stream (small batches).
     T *SC;
+    // Candidate checkpoints (null = off): [tile][segment][candidate][NX][64], the state of every
+    // line-search candidate at time step COMMIT_SEG * segment, segment = 0 .. ceil((N-1)/COMMIT_SEG) - 1.
+    // Written by the (single-stage) line search, read by commit_segments_kernel.
+    T *CK;
     const T *centers, *radius;
     const T *ltvA, *ltvB;
     T *hist_cost;
@@ -1233,10 +1248,13 @@ __device__ __forceinline__ T candidate_total(const P &p, const T (&x)[M::NX], co
 // time step, NX fewer values of traffic.
 // TC (with REROLL): the previous trajectory's sine/cosine pairs come from SCp (Params::SC), which
 // turns its re-rollout into a few multiply-adds.
-template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool REROLL, bool FAST, bool TC = false, class P>
+// CKPT: the state of every candidate at the start of every segment of COMMIT_SEG time steps is
+// stored to CKp (this problem's first checkpoint slot, see Params::CK) by the lanes with `ck_store`.
+template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool REROLL, bool FAST, bool TC = false, bool CKPT = false, class P>
 __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T *Rt, const T *Ut, const T *Kp, const T *kp,
                                                 const T *Cp, const T *Dp, int al, bool active, T Jcur, int base0, int end,
-                                                int &best, T &best_cost, bool &bad, const T *SCp = nullptr) {
+                                                int &best, T &best_cost, bool &bad, const T *SCp = nullptr, T *CKp = nullptr,
+                                                bool ck_store = false) {
     constexpr int NX = M::NX, NU = M::NU;
     const int T1 = p.N - 1;
     auto load_row = [&](int t, FwdRow<T, NX, NU> &r) {
@@ -1282,9 +1300,7 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
         for (int i = 0; i < NX; ++i) xq[i] = Xt[i * TILE];
         FwdRow<T, NX, NU> nxt;
         load_row(0, nxt);
-        for (int t = 0; t < T1; ++t) {
-            FwdRow<T, NX, NU> r = nxt;
-            if (t + 1 < T1) load_row(t + 1, nxt);
+        auto one_step = [&](int t, FwdRow<T, NX, NU> &r) {
             if (REROLL) {
 #pragma unroll
                 for (int i = 0; i < NX; ++i) r.xp[i] = xq[i];
@@ -1296,6 +1312,43 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
                 model_step<FAST, TC, M>(p, t, xq, r.up, xqn, r.s, r.c, bad);
 #pragma unroll
                 for (int i = 0; i < NX; ++i) xq[i] = xqn[i];
+            }
+        };
+        if (CKPT) {
+            // The horizon in segments.  The first step of a segment also stores the candidates'
+            // states (the segment's checkpoint), AFTER it has issued the loads of the next row: loads
+            // and stores retire in order, so stores issued before them would make the next step wait
+            // for their acknowledgement as well.
+            int t = 0;
+            for (int seg = 0; t < T1; ++seg) {
+                {
+                    FwdRow<T, NX, NU> r = nxt;
+                    if (t + 1 < T1) load_row(t + 1, nxt);
+                    if (ck_store) {
+#pragma unroll
+                        for (int j = 0; j < A; ++j) {
+                            const int a = base + al * A + j;
+                            if (a < CK_CANDIDATES) {
+#pragma unroll
+                                for (int i = 0; i < NX; ++i) CKp[(size_t)((seg * CK_CANDIDATES + a) * NX + i) * TILE] = x[j][i];
+                            }
+                        }
+                    }
+                    one_step(t, r);
+                    ++t;
+                }
+                const int tend = seg * COMMIT_SEG + COMMIT_SEG < T1 ? seg * COMMIT_SEG + COMMIT_SEG : T1;
+                for (; t < tend; ++t) {
+                    FwdRow<T, NX, NU> r = nxt;
+                    if (t + 1 < T1) load_row(t + 1, nxt);
+                    one_step(t, r);
+                }
+            }
+        } else {
+            for (int t = 0; t < T1; ++t) {
+                FwdRow<T, NX, NU> r = nxt;
+                if (t + 1 < T1) load_row(t + 1, nxt);
+                one_step(t, r);
             }
         }
         // terminal term (ilqr.py:44-45)
@@ -1342,7 +1395,7 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
 // them while candidates remain is appended to a device-side list; stage two
 // (evaluate_listed_kernel) walks that list with the remaining candidates.  Candidates are still
 // examined in increasing index order, so the result is that of the serial search.
-template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool REROLL, bool TC = false>
+template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool REROLL, bool TC = false, bool CKPT = false>
 __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T, M::NX, M::NU> p, int end) {
     constexpr int NX = M::NX, NU = M::NU;
     constexpr int PPW = 64 / L; // problems per wave
@@ -1374,8 +1427,10 @@ __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T,
     T best_cost;
     bool bad = false;
     const T *SCp = (REROLL && TC) ? tile_ptr(p.SC, tile, T1 * 2, ln) : nullptr;
-    evaluate_rounds<T, M, DIAG, BARRIER, L, A, REROLL, true, TC>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, 0, end, best, best_cost, bad,
-                                                                  SCp);
+    const int nseg = (T1 + COMMIT_SEG - 1) / COMMIT_SEG;
+    T *CKp = CKPT ? tile_ptr(p.CK, tile, nseg * CK_CANDIDATES * NX, ln) : nullptr;
+    evaluate_rounds<T, M, DIAG, BARRIER, L, A, REROLL, true, TC, CKPT>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, 0, end, best, best_cost,
+                                                                        bad, SCp, CKp, true);
     // an angle outside the fast trigonometric range anywhere in the wave: redo with the library
     // routine; a problem one of whose lanes saw such an angle takes the redone result (and tells
     // the commit kernel to use the library routine too), the others keep theirs, so a problem's
@@ -1387,8 +1442,9 @@ __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T,
         int best2;
         T best_cost2;
         bool bad2 = false;
-        evaluate_rounds<T, M, DIAG, BARRIER, L, A, REROLL, false, TC>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, 0, end, best2, best_cost2,
-                                                                       bad2, SCp);
+        // (the checkpoints of the problems that take the redone result are replaced, the others' stay)
+        evaluate_rounds<T, M, DIAG, BARRIER, L, A, REROLL, false, TC, CKPT>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, 0, end, best2,
+                                                                             best_cost2, bad2, SCp, CKp, pbad);
         best = pbad ? best2 : best;
         best_cost = pbad ? best_cost2 : best_cost;
     }
@@ -2117,6 +2173,133 @@ __global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, i
     commit_sweep<T, M, PF, REROLL, true, TC>(p, Xt, Ut, Kp, kp, trash, alpha, roll && !slow, keep_ok, pend, slow, SCt);
     if (__ballot(slow) != 0ull)
         commit_sweep<T, M, 1, REROLL, false, TC>(p, Xt, Ut, Kp, kp, trash, alpha, slow, keep_ok, pend, !slow, SCt);
+}
+
+// ---------------------------------------------------------------- commit, all segments at once
+// The rollout of the accepted step size is a recurrence over the horizon, and with one lane per
+// problem a small batch leaves most of the chip idle for its whole length.  With the candidates'
+// states at the segment starts at hand (Params::CK, kept by the line search) every segment of
+// COMMIT_SEG time steps can be rolled out on its own: wave (tile, segment) starts from the accepted
+// candidate's checkpoint and executes the instruction sequence of commit_sweep for its steps, so
+// the trajectory comes out bit for bit as from the sequential kernel, after COMMIT_SEG dependent
+// steps instead of N-1.  Segment `seg` owns the time steps [t0, t1): it writes the inputs (and the
+// sine/cosine pairs) of those steps and the states of the time steps t0 .. t1-1 (t0 from its
+// checkpoint; the last segment also the terminal state), and reads the previous states of the
+// same steps before it overwrites them: no row is shared between waves.
+// The wave of segment 0 also does the per-problem bookkeeping of commit_kernel.
+template <typename T, class M, bool FAST, bool TC, class P>
+__device__ __forceinline__ void commit_segment_sweep(const P &p, T *Xt, T *Ut, const T *Kp, const T *kp, T *SCt, T alpha, const T (&xs)[M::NX],
+                                                     int t0, int t1, bool store, bool first) {
+    constexpr int NX = M::NX, NU = M::NU, S = COMMIT_SEG, RING = 4;
+    static_assert(S % RING == 0, "the segment length must be a multiple of the prefetch ring");
+    const int T1 = p.N - 1;
+    struct Row {
+        T K[NU][NX], k[NU], xp[NX], up[NU];
+    };
+    // a wave lives for S steps only, so nothing but its own loads in flight hides the memory latency:
+    // the rows of the next RING steps are always under way, and no load sits behind a branch (past
+    // the end of the segment its last row is fetched again)
+    auto load_row = [&](int tt, Row &r) {
+        const int t = tt < t1 ? tt : t1 - 1;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            r.k[i] = kp[(t * NU + i) * TILE];
+            r.up[i] = Ut[(t * NU + i) * TILE];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) r.K[i][j] = Kp[((t * NU + i) * NX + j) * TILE];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) r.xp[i] = Xt[(t * NX + i) * TILE];
+    };
+    T x[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = xs[i];
+    Row ring[RING];
+#pragma unroll
+    for (int q = 0; q < RING; ++q) load_row(t0 + q, ring[q]); // before any store: these states are the previous trajectory's
+    if (store && !first) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Xt[(t0 * NX + i) * TILE] = x[i];
+    }
+    bool bad = false;
+    for (int q0 = 0; q0 < S; q0 += RING)
+#pragma unroll
+    for (int qr = 0; qr < RING; ++qr) {
+        const int t = t0 + q0 + qr;
+        Row r = ring[qr];
+        load_row(t + RING, ring[qr]); // row t+RING is read before step t+RING-1 stores to it
+        T un[NU], xn[NX], sn = T(0), cn = T(0);
+        control_update<T, M>(p, alpha, x, r.xp, r.up, r.K, r.k, un);
+        model_step<FAST, false, M>(p, t, x, un, xn, sn, cn, bad);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = xn[i];
+        if (store && t < t1) {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) Ut[(t * NU + i) * TILE] = un[i];
+            if (TC) {
+                SCt[(t * 2 + 0) * TILE] = sn;
+                SCt[(t * 2 + 1) * TILE] = cn;
+            }
+            if (t + 1 < t1 || t + 1 == T1) { // the next segment writes its own first state
+#pragma unroll
+                for (int i = 0; i < NX; ++i) Xt[((t + 1) * NX + i) * TILE] = xn[i];
+            }
+        }
+    }
+}
+
+template <typename T, class M, bool TC>
+__global__ __launch_bounds__(64) void commit_segments_kernel(Params<T, M::NX, M::NU> p, int it, int nseg) {
+    constexpr int NX = M::NX, NU = M::NU;
+    const int tile = blockIdx.x / nseg, seg = blockIdx.x % nseg, ln = threadIdx.x;
+    const int b0 = tile * 64 + ln;
+    const bool valid = b0 < p.B;
+    const int b = valid ? b0 : p.B - 1;
+    // (the wave of segment 0 may already have marked a problem without an accepted step as
+    // converged while another wave reads the flag: such a problem has idx < 0 and is not rolled
+    // out either way; the flag of a problem that is rolled out does not change)
+    const int idx = p.alpha_idx[b];
+    const bool roll = valid && idx >= 0 && p.converged[b] == 0;
+    const int T1 = p.N - 1;
+    const int slow_bits = p.slow_trig[b];
+    const bool slow = roll && (slow_bits & 1) != 0;
+    if (seg == 0) {
+        // per-problem outcome, as in commit_kernel
+        const bool act0 = valid && p.converged[b] == 0;
+        if (act0) {
+            p.slow_trig[b] = (slow_bits & 1) | (roll ? (4 | (slow ? 2 : 0)) : 0);
+            p.iters[b] += 1;
+            const T Jn = roll ? p.Jtry[b] : p.J[b];
+            if (roll) {
+                p.J[b] = Jn;
+                if (p.status && !(fabs_(Jn) < inf_<T>())) p.status[b] |= ILQR_STATUS_NONFINITE_;
+            } else {
+                p.converged[b] = 1;
+            }
+            if (it < p.hist_cap) {
+                if (p.hist_cost) p.hist_cost[size_t(it) * p.hist_stride + b] = Jn;
+                if (p.hist_alpha) p.hist_alpha[size_t(it) * p.hist_stride + b] = idx;
+            }
+        }
+    }
+    if (__ballot(roll) == 0ull) return;
+    T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
+    T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
+    const T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
+    const T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    T *SCt = TC ? tile_ptr(p.SC, tile, T1 * 2, ln) : nullptr;
+    const T *CKp = tile_ptr(p.CK, tile, nseg * CK_CANDIDATES * NX, ln);
+    const int t0 = seg * COMMIT_SEG, t1 = t0 + COMMIT_SEG < T1 ? t0 + COMMIT_SEG : T1;
+    const int cand = roll ? idx : 0;
+    const T alpha = pow2_neg<T>(cand);
+    T xs[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+        xs[i] = seg == 0 ? Xt[i * TILE] : CKp[(size_t)((seg * CK_CANDIDATES + cand) * NX + i) * TILE];
+    // per problem: the fast sweep writes nothing for a problem that needs the library sine/cosine
+    // and the second sweep (rare) writes only those, as in commit_kernel
+    if (__ballot(roll && !slow) != 0ull) commit_segment_sweep<T, M, true, TC>(p, Xt, Ut, Kp, kp, SCt, alpha, xs, t0, t1, roll && !slow, seg == 0);
+    if (__ballot(slow) != 0ull) commit_segment_sweep<T, M, false, TC>(p, Xt, Ut, Kp, kp, SCt, alpha, xs, t0, t1, slow, seg == 0);
 }
 
 // ---------------------------------------------------------------- active-set compaction

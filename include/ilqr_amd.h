@@ -105,6 +105,12 @@ typedef struct ilqr_desc {
                                   instructions per iteration, more traffic); 0 = auto (on up to 16384 problems, where
                                   the passes are bound by their instruction stream); < 0: off.  Built-in models without
                                   compaction only; ignored otherwise. */
+    int32_t segment_commit;    /* > 0: the line search keeps the state of every candidate every 32 time steps in `work`
+                                  and the commit rolls the accepted candidate out in all segments of 32 steps at once
+                                  (same bits; the sequential commit leaves a small batch's chip idle for N-1 dependent
+                                  steps); 0 = auto (on up to 8192 problems); < 0: off.  Needs a single-stage line
+                                  search with 4 or more lanes per problem, n <= 8, no compaction, one stream. */
+    int32_t reserved3;
     double dt;               /* system.dt (systems.py:30); the solver's own dt argument is unused (ilqr.py:20) */
     double lm_parameter;     /* ilqr.py:30, added to Vxx (ilqr.py:95) */
     double alpha_floor;      /* 1e-4 (ilqr.py:71) or alpha_terminal (cilqr.py:41) */

@@ -388,3 +388,44 @@ def solve_qp_riccati(system, target, x0, A, B, c, G, lo, hi, umin, umax, u_start
         if mu <= tol and rp_max <= tol and np.abs(du).max() <= 1e-8:
             break
     return u, xs, it + 1
+
+
+def min_relaxation(system, x0, A, B, c, G, lo, hi, umin, umax):
+    """Feasibility certificate for the QP of sqp.py:87-134, independent of any QP method: smallest t >= 0 such that lo - t <= G x <= hi + t (steps 1..N-1) and umin - t <= u <= umax + t
+    has a solution with x_{i+1} = A_i x_i + B_i u_i + c_i, x_0 given."""
+    from scipy.optimize import linprog
+    T, n, m = A.shape[0], A.shape[1], B.shape[2]
+    N = T + 1
+    Phi = np.zeros((N, n, T * m))
+    phi = np.zeros((N, n))
+    phi[0] = x0
+    for i in range(T):
+        Phi[i + 1] = A[i] @ Phi[i]
+        Phi[i + 1][:, i * m:(i + 1) * m] += B[i]
+        phi[i + 1] = A[i] @ phi[i] + c[i]
+    rows, rhs = [], []
+    for i in range(1, N):
+        for j in range(2):
+            g = G[i, j] @ Phi[i]
+            off = G[i, j] @ phi[i]
+            if np.isfinite(hi[i, j]):
+                rows.append(np.concatenate([g, [-1.0]]))
+                rhs.append(hi[i, j] - off)
+            if np.isfinite(lo[i, j]):
+                rows.append(np.concatenate([-g, [-1.0]]))
+                rhs.append(off - lo[i, j])
+    for i in range(T):
+        for j in range(m):
+            e = np.zeros(T * m + 1)
+            e[i * m + j], e[-1] = 1.0, -1.0
+            if np.isfinite(umax[j]):
+                rows.append(e.copy())
+                rhs.append(umax[j])
+            e[i * m + j] = -1.0
+            if np.isfinite(umin[j]):
+                rows.append(e.copy())
+                rhs.append(-umin[j])
+    cost = np.zeros(T * m + 1)
+    cost[-1] = 1.0
+    res = linprog(cost, A_ub=np.array(rows), b_ub=np.array(rhs), bounds=[(None, None)] * (T * m) + [(0, None)], method="highs")
+    return float(res.x[-1]) if res.status == 0 else float("nan")

@@ -837,6 +837,68 @@ def test_subclass_with_own_dynamics_is_not_solved_with_the_builtin_kernels(ilqr_
     assert np.array_equal(o.min_cost, o2.min_cost)
 
 
+def test_time_parallel_commit_does_not_change_a_bit(ilqr_cls, oracle):
+    """Small batches roll the accepted step out in segments of 8 time steps, all at once, from the
+    states the line search kept of every candidate at the segment starts.  Every output must equal
+    the sequential commit's, bit for bit: horizons that are and are not multiples of the segment
+    length, shorter than one segment, a ragged batch, fp32, the constrained solver with the barrier,
+    a run-time compiled model, a heading outside the fast sine/cosine range, with and without the
+    sine/cosine cache."""
+    from ilqr_amd import problems
+    for N, B in ((110, 150), (9, 70), (33, 5), (66, 130), (3, 9), (200, 64)):
+        p = problems.car_batch(B, N)
+        if B > 7:
+            p["init_states"][7, :, 3] += 3.0e6
+            p["target_states"][7, :, 3] += 3.0e6
+        ref = _solve_batch(ilqr_cls, p, segment_commit=-1, trig_cache=-1)
+        Kr, kr = ref.K.copy(), ref.k.copy()
+        for kw in (dict(trig_cache=1), dict(trig_cache=-1), dict(lanes_per_problem=16, alphas_per_lane=1),
+                   dict(lanes_per_problem=4, alphas_per_lane=4, trig_cache=1), dict(lanes_per_problem=8, alphas_per_lane=2)):
+            o = _solve_batch(ilqr_cls, p, segment_commit=1, **kw)
+            for key in ("states", "inputs", "min_cost", "iterations", "converge", "status"):
+                assert np.array_equal(getattr(o, key), getattr(ref, key), equal_nan=True), (N, B, kw, key)
+            assert np.array_equal(o.alpha_history, ref.alpha_history)
+            assert np.array_equal(o.cost_history, ref.cost_history, equal_nan=True)
+            assert np.array_equal(o.K, Kr) and np.array_equal(o.k, kr), (N, B, kw)
+    p = problems.car_batch(90, 70)
+    a = _solve_batch(ilqr_cls, p, segment_commit=-1, dtype=np.float32)
+    b = _solve_batch(ilqr_cls, p, segment_commit=1, dtype=np.float32)
+    assert np.array_equal(a.states, b.states) and np.array_equal(a.inputs, b.inputs) and np.array_equal(a.min_cost, b.min_cost)
+    # constrained solver, barrier on: 8 step sizes in one round
+    from ilqr_amd.cilqr import iterative_LQR as CILQR
+    from ilqr_amd.constraints import BubbleConstraint
+    car, tg, ui = cilqr_problem(80, 4)
+    Bc = 40
+    tgs = np.stack([tg + 0.05 * b for b in range(Bc)])
+    centers, radius, vb = problems.bubbles_for(tgs, radius=6.0, vel_bounds=(-1.0, 14.0))
+    con = BubbleConstraint(80)
+    con.setup(centers, radius, vb)
+    outs = []
+    for sc in (-1, 1):
+        opt = CILQR(car, tgs, car.dt, history=True, segment_commit=sc)
+        opt.inputs = np.stack([ui] * Bc)
+        opt.maxIter = 20
+        opt.set_barrier(con, mu=50.0, delta=0.5)
+        opt()
+        outs.append(opt)
+    assert np.array_equal(outs[0].states, outs[1].states) and np.array_equal(outs[0].min_cost, outs[1].min_cost)
+    assert np.array_equal(outs[0].cost_history, outs[1].cost_history, equal_nan=True)
+    # a run-time compiled model
+    from ilqr_amd.user_models import KinematicBicycle
+    q = problems.bicycle_batch(33, 60)
+    outs = []
+    for sc in (-1, 1):
+        s = KinematicBicycle()
+        s.set_cost(problems.BICYCLE_Q.copy(), problems.BICYCLE_R.copy())
+        s.set_control_limit(*problems.BICYCLE_LIMITS)
+        o = ilqr_cls(s, q["target_states"], s.dt, history=True, segment_commit=sc)
+        o.inputs, o.states = q["init_inputs"].copy(), q["init_states"].copy()
+        o()
+        outs.append(o)
+    for key in ("states", "inputs", "min_cost", "iterations", "converge"):
+        assert np.array_equal(getattr(outs[0], key), getattr(outs[1], key)), key
+
+
 def test_sine_cosine_cache_does_not_change_a_bit(ilqr_cls):
     """For small batches the commits keep the sine/cosine of the heading of every step in memory and
     the backward pass and the line search read them instead of evaluating them again: every output

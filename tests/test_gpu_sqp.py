@@ -99,7 +99,7 @@ def test_batch_matches_oracle_and_does_not_depend_on_sharding():
     opt()
     assert opt.states.shape == (B, N, 4) and opt.min_cost.shape == (B,)
     ok = opt.status == 0
-    assert ok.mean() > 0.8
+    assert ok.mean() >= 0.95
     for b in np.flatnonzero(ok)[:10]:
         con = BubbleConstraint(N)
         con.setup(p["centers"][b], p["radius"][b], p["vel_bounds"])
@@ -115,8 +115,18 @@ def test_batch_matches_oracle_and_does_not_depend_on_sharding():
         c = so.cost(car, p["target_states"][b], opt.states[b], opt.inputs[b])
         assert abs(c - opt.min_cost[b]) <= 1e-11 * abs(c)
     # problems whose linearised rows cannot be met are flagged, stop, and keep a valid trajectory
+    # (the reference hands such a QP to OSQP, which reports it infeasible and returns no solution:
+    # the search of sqp.py:156-171 then rejects every step and sets `converge` as well)
     bad = ~ok
     assert np.all(opt.status[bad] == 8) and np.all(opt.converge[bad]) and np.all(np.isfinite(opt.states))
+    # ... and only those: for every flagged problem an LP solver certifies that the rows of the QP at
+    # the returned trajectory (its linearisation point: the step was zero) have no common point
+    umin, umax = np.array(car.control_lower_limit, float), np.array(car.control_upper_limit, float)
+    for b in np.flatnonzero(bad):
+        con = BubbleConstraint(N)
+        con.setup(p["centers"][b], p["radius"][b], p["vel_bounds"])
+        A, Bm, c, G, lo, hi = so.qp_data(car, con, p["target_states"][b], opt.states[b], opt.inputs[b])
+        assert so.min_relaxation(car, p["target_states"][b, 0], A, Bm, c, G, lo, hi, umin, umax) > 1e-6
     # shard invariance: two halves (ragged against the 64-problem tiles) give the same bits
     parts = []
     for sl in (slice(0, 37), slice(37, B)):

@@ -2,7 +2,9 @@
 """Whole-solve timings of the secondary workloads (the ones bench.py does not quote): one JSON
 line per configuration, inputs resident in HBM, time = ilqr_solve on the device, median of reps.
 
-    python tools/bench_configs.py [--reps 3] [--only car4096,cilqr16384,car65536_f32,ltv_f64,ltv_f32,sqp16384,sqp65536]
+    python tools/bench_configs.py [--reps 3] [--only car4096,car8192,car16384,car32768,cilqr16384,car65536_f32,ltv_f64,ltv_f32,sqp16384,sqp65536]
+
+car8192 / car16384 / car32768 are the per-GPU shards of the 65536-problem headline batch on 8 / 4 / 2 GPUs.
 """
 import argparse
 import json
@@ -31,8 +33,8 @@ def car_system(qf_scale=None):
 
 
 def build(name):
-    if name in ("car4096", "car16384", "car65536_f32"):
-        B = {"car4096": 4096, "car16384": 16384, "car65536_f32": 65536}[name]
+    if name in ("car4096", "car8192", "car16384", "car32768", "car65536_f32"):
+        B = {"car4096": 4096, "car8192": 8192, "car16384": 16384, "car32768": 32768, "car65536_f32": 65536}[name]
         p = problems.car_batch(B, 200)
         opt = iterative_LQR(car_system(), p["target_states"], 0.2, dtype=np.float32 if name.endswith("f32") else np.float64)
         opt.inputs, opt.states = p["init_inputs"], p["init_states"]
@@ -77,7 +79,7 @@ def build(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--only", default="car4096,car16384,cilqr16384,car65536_f32,ltv_f64,ltv_f32")
+    ap.add_argument("--only", default="car4096,car8192,car16384,car32768,cilqr16384,car65536_f32,ltv_f64,ltv_f32,sqp16384")
     a = ap.parse_args()
     import torch
     for name in a.only.split(","):
