@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--repack-every", type=int, default=None,
                     help="active-set compaction period; default = what ilqr_solve picks: 8 from 32768 problems per GPU on, else none")
     ap.add_argument("--no-repack", action="store_true")
+    ap.add_argument("--segment-commit", type=int, default=0, help="time-parallel commit: 0 = the library's choice, -1 off, 1 on")
+    ap.add_argument("--trig-cache", type=int, default=0, help="sine/cosine cache: 0 = the library's choice, -1 off, 1 on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=65536, help="upper bound on problems in the CPU baseline sample")
     args = ap.parse_args()
@@ -97,7 +99,8 @@ def main():
     repack_every = 0 if args.no_repack else (args.repack_every if args.repack_every is not None else (8 if B >= 32768 else 0))
     # the handle is created with the same period, so that it holds the workspace ilqr_repack needs
     opt = iterative_LQR(car, p["target_states"], car.dt, history=True, dtype=np_dtype,
-                        repack_every=repack_every if repack_every > 0 else -1, **kw)
+                        repack_every=repack_every if repack_every > 0 else -1, segment_commit=args.segment_commit,
+                        trig_cache=args.trig_cache, **kw)
     opt.inputs, opt.states = p["init_inputs"], p["init_states"]
     dev = opt.upload()
     X0, U0 = dev.X.clone(), dev.U.clone()

@@ -238,6 +238,8 @@ template <typename T, int NX, int NU> static Params<T, NX, NU> make_params(const
 #endif
 constexpr int PF_BACKWARD = ILQR_PF_BACKWARD;
 constexpr int PF_COMMIT = ILQR_PF_COMMIT;
+// a row of the 12-state model is 56 values: a second row in flight spills (1148 bytes of scratch per lane)
+template <int NX> constexpr int pf_commit() { return NX > 8 ? 1 : PF_COMMIT; }
 
 template <typename T, template <typename> class MT, bool DIAG> struct Launch {
     using M = MT<T>;
@@ -460,11 +462,11 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
         if constexpr (HAS_TRIG) {
             // every commit of a handle with the cache keeps it up to date, whether or not it can read it yet
             if (c.trig && c.ws.slot2orig == nullptr) {
-                hipLaunchKernelGGL((commit_kernel<T, M, PF_COMMIT, REROLL, true>), dim3((c.count + 63) / 64), dim3(64), 0, s, p, it);
+                hipLaunchKernelGGL((commit_kernel<T, M, pf_commit<NX>(), REROLL, true>), dim3((c.count + 63) / 64), dim3(64), 0, s, p, it);
                 return hipGetLastError();
             }
         }
-        hipLaunchKernelGGL((commit_kernel<T, M, PF_COMMIT, REROLL>), dim3((c.count + 63) / 64), dim3(64), 0, s, p, it);
+        hipLaunchKernelGGL((commit_kernel<T, M, pf_commit<NX>(), REROLL>), dim3((c.count + 63) / 64), dim3(64), 0, s, p, it);
         return hipGetLastError();
     }
     // number of candidates of the first line-search stage; >= n_alphas: there is no second stage
