@@ -290,7 +290,10 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
                 auto p = make_params<T, NX, NU>(c);
                 const int tiles = (c.count + 63) / 64;
                 const int blocks = ((tiles + 7) / 8) * 8 * 64;
-                hipLaunchKernelGGL((ltv12x4_backward_mfma_kernel<T, false>), dim3(blocks), dim3(64), 0, s, p);
+                if constexpr (std::is_same<T, double>::value)
+                    hipLaunchKernelGGL(ltv12x4_backward_staged_kernel, dim3((c.count + 15) / 16), dim3(1024), 0, s, p);
+                else
+                    hipLaunchKernelGGL((ltv12x4_backward_mfma_kernel<T, false>), dim3(blocks), dim3(64), 0, s, p);
                 hipLaunchKernelGGL((ltv12x4_backward_mfma_kernel<T, true>), dim3(blocks), dim3(64), 0, s, p);
                 return hipGetLastError();
             }

@@ -925,12 +925,65 @@ typedef double v4f64_ __attribute__((ext_vector_type(4)));
 // One reverse sweep for the problem of this wave.  ASSUME_PD: branch-free LDL' solve of Quu that
 // only raises `bad` when a pivot is not positive; the kernel then repeats the sweep with the
 // pivoted-LU fallback (numpy.linalg.inv semantics, status bits).
+// Reciprocal by two Newton steps on the hardware estimate (the matrix-unit kernels agree with the
+// scalar ones to rounding only, so the correctly rounded division is not needed here): 5
+// instructions instead of the 10 of an IEEE division, four times per time step.
+__device__ __forceinline__ double fast_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ float fast_rcp(float d) { return 1.0f / d; }
+
+// Branch-free L D L' solve of the 4 x 4 system Quu [k | K_c] = rhs for the matrix-unit kernels
+// (same elimination order as solve_quu, reciprocals by fast_rcp); `bad` if a pivot is not positive.
+template <typename T> __device__ __forceinline__ void solve_quu4_fast(const T (&A)[4][4], T (&Bm)[4][2], bool &bad) {
+    T L[4][4], d[4], dinv[4];
+    bool pd = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        T dj = A[j][j];
+#pragma unroll
+        for (int q = 0; q < j; ++q) dj = fma_(-(L[j][q] * L[j][q]), d[q], dj);
+        pd = pd && (dj > T(0));
+        d[j] = dj;
+        dinv[j] = fast_rcp(dj);
+#pragma unroll
+        for (int i = j + 1; i < 4; ++i) {
+            T s = A[i][j];
+#pragma unroll
+            for (int q = 0; q < j; ++q) s = fma_(-(L[i][q] * L[j][q]), d[q], s);
+            L[i][j] = s * dinv[j];
+        }
+    }
+    bad = bad || !pd;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        T y[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            T s = Bm[i][c];
+#pragma unroll
+            for (int q = 0; q < i; ++q) s = fma_(-L[i][q], y[q], s);
+            y[i] = s;
+        }
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {
+            T s = y[i] * dinv[i];
+#pragma unroll
+            for (int q = i + 1; q < 4; ++q) s = fma_(-L[q][i], Bm[q][c], s);
+            Bm[i][c] = s;
+        }
+    }
+}
+
 template <bool ASSUME_PD>
 __device__ __forceinline__ int ltv12x4_backward_sweep(const Params<double, 12, 4> &p, double *sh, int slot, int lane, bool &bad) {
     constexpr int NX = 12, NU = 4;
     const int c = lane & 15, g = lane >> 4;
     const int T1 = p.N - 1;
-    const int tile = slot >> 6, ln = slot & 63;
+    const int tile = slot >> 6, ln = slot & 63; // one problem per wave: uniform
     const double *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
     const double *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
     const double *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
@@ -938,55 +991,61 @@ __device__ __forceinline__ int ltv12x4_backward_sweep(const Params<double, 12, 4
     double *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
     const bool isx = c < NX;
     const int cu = isx ? 0 : c - NX;
-    // per-lane constants: weight of this lane's component of [x; u], diagonal positions of the tiles
+    // Per-lane constants, fixed before the time loop: the weight of this lane's component of
+    // [x; u], the diagonal terms it adds to its registers of the tiles, and for every row it reads
+    // or writes a base pointer and a stride per time step (state lanes and input lanes read
+    // different arrays: with a pointer and a stride per lane no load or store sits behind a branch).
     const double lw = isx ? p.Q2[c * NX + c] : p.R2[cu * NU + cu];
-    bool dpos[4];
+    double lwd[4], lmd[3];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dpos[r] = (g + 4 * r == c);
-    auto load_xu = [&](int t) { return isx ? Xt[(size_t)(t * NX + c) * TILE] : Ut[(size_t)(t * NU + cu) * TILE]; };
-    auto load_xr = [&](int t) { return isx ? Rt[(size_t)(t * NX + c) * TILE] : 0.0; };
-    auto load_F = [&](int t, int kk) { // F[g + 4 kk][c] of step t
-        const int k = g + 4 * kk;
-        return isx ? p.ltvA[(size_t)t * NX * NX + k * NX + c] : p.ltvB[(size_t)t * NX * NU + k * NU + cu];
-    };
+    for (int r = 0; r < 4; ++r) lwd[r] = (g + 4 * r == c) ? lw : 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) lmd[r] = (g + 4 * r == c && isx) ? p.lm : 0.0;
+    const double *xuP = isx ? Xt + (size_t)c * TILE : Ut + (size_t)cu * TILE;
+    const double *xrP = Rt + (size_t)(isx ? c : 0) * TILE; // input lanes read a valid row and use zero
+    const unsigned xuS = isx ? NX * TILE : NU * TILE;
+    const double *FP = isx ? p.ltvA + g * NX + c : p.ltvB + g * NU + cu; // F[g + 4 kk][c]: + kk * FK per call
+    const unsigned FS = isx ? NX * NX : NX * NU, FK = isx ? 4 * NX : 4 * NU;
+    // gains: state lanes store K[g][c], the input lanes of group 0 store k[cu], the rest nothing
+    double *outP = isx ? Kp + (size_t)(g * NX + c) * TILE : kp + (size_t)cu * TILE;
+    const unsigned outS = isx ? NU * NX * TILE : NU * TILE;
+    const bool outOn = isx || g == 0;
     // terminal condition (ilqr.py:79-82): Vx = 2 Qf (x - xref), Vxx = 2 Qf
     double vx = isx ? p.Qf2[c * NX + c] * (Xt[(size_t)(T1 * NX + c) * TILE] - Rt[(size_t)(T1 * NX + c) * TILE]) : 0.0;
     double Vt[3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) Vt[r] = (isx && dpos[r]) ? p.Qf2[c * NX + c] : 0.0;
+    for (int r = 0; r < 3; ++r) Vt[r] = (isx && g + 4 * r == c) ? p.Qf2[c * NX + c] : 0.0;
     int status = 0;
     // the rows of the next PFL steps are in flight (a register ring; the loop is unrolled by PFL)
     constexpr int PFL = 4;
     double rxu[PFL], rxr[PFL], rF[PFL][3];
+    auto load_step = [&](int t, int s) {
+        rxu[s] = xuP[(size_t)t * xuS];
+        rxr[s] = xrP[(size_t)t * (NX * TILE)];
+        const double *f = FP + (size_t)t * FS;
 #pragma unroll
-    for (int s = 0; s < PFL; ++s) {
-        const int ts = T1 - 1 - s > 0 ? T1 - 1 - s : 0;
-        rxu[s] = load_xu(ts);
-        rxr[s] = load_xr(ts);
+        for (int kk = 0; kk < 3; ++kk) rF[s][kk] = f[kk * FK];
+    };
 #pragma unroll
-        for (int kk = 0; kk < 3; ++kk) rF[s][kk] = load_F(ts, kk);
-    }
+    for (int s = 0; s < PFL; ++s) load_step(T1 - 1 - s > 0 ? T1 - 1 - s : 0, s);
     for (int tb = T1 - 1; tb >= 0; tb -= PFL)
 #pragma unroll
     for (int s = 0; s < PFL; ++s) {
         const int t = tb - s;
         if (t < 0) break;
-        const double xu_c = rxu[s], xr_c = rxr[s], F0 = rF[s][0], F1 = rF[s][1], F2 = rF[s][2];
-        const int tn = t - PFL > 0 ? t - PFL : 0;
-        rxu[s] = load_xu(tn);
-        rxr[s] = load_xr(tn);
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) rF[s][kk] = load_F(tn, kk);
+        const double xu_c = rxu[s], xr_c = isx ? rxr[s] : 0.0, F0 = rF[s][0], F1 = rF[s][1], F2 = rF[s][2];
+        load_step(t - PFL > 0 ? t - PFL : 0, s);
         // first-order terms: [Qx; Qu] = [lx; lu] + F' Vx (ilqr.py:93-94)
         double part = F0 * __shfl(vx, g) + F1 * __shfl(vx, g + 4) + F2 * __shfl(vx, g + 8);
         part += __shfl_xor(part, 16);
         part += __shfl_xor(part, 32);
         const double qv = fma_(lw, xu_c - xr_c, part);
-        // W = (Vxx + lm I) F
+        // W = (Vxx + lm I) F.  Lanes c >= 12 hold rows 12..15 of the left factor, which only produce
+        // rows of the result that no later product reads: they need no masking anywhere below.
         v4f64_ W = {0.0, 0.0, 0.0, 0.0};
-        W = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[0] + (dpos[0] && isx ? p.lm : 0.0), F0, W, 0, 0, 0);
-        W = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[1] + (dpos[1] && isx ? p.lm : 0.0), F1, W, 0, 0, 0);
-        W = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[2] + (dpos[2] && isx ? p.lm : 0.0), F2, W, 0, 0, 0);
+        W = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[0] + lmd[0], F0, W, 0, 0, 0);
+        W = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[1] + lmd[1], F1, W, 0, 0, 0);
+        W = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[2] + lmd[2], F2, W, 0, 0, 0);
         // G = F' W in both layouts
         v4f64_ TG = {0.0, 0.0, 0.0, 0.0}, DG = {0.0, 0.0, 0.0, 0.0};
         TG = __builtin_amdgcn_mfma_f64_16x16x4f64(W[0], F0, TG, 0, 0, 0);
@@ -997,9 +1056,9 @@ __device__ __forceinline__ int ltv12x4_backward_sweep(const Params<double, 12, 4
         DG = __builtin_amdgcn_mfma_f64_16x16x4f64(F2, W[2], DG, 0, 0, 0);
         // + lxx = 2Q, luu = 2R on the diagonal (ilqr.py:91-92)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) TG[r] += dpos[r] ? lw : 0.0;
-        const double qg = DG[3] + (dpos[3] ? lw : 0.0); // Qux[g][c] (c < 12), Quu[g][c - 12] (c >= 12)
-        __syncthreads();                                // the previous step has read sh
+        for (int r = 0; r < 4; ++r) TG[r] += lwd[r];
+        const double qg = DG[3] + lwd[3]; // Qux[g][c] (c < 12), Quu[g][c - 12] (c >= 12)
+        __syncthreads();                  // the previous step has read sh
         sh[g * 16 + c] = qg;
         if (g == 0) sh[64 + c] = qv;
         __syncthreads();
@@ -1012,18 +1071,22 @@ __device__ __forceinline__ int ltv12x4_backward_sweep(const Params<double, 12, 4
             rhs[i][0] = -Qu[i];
             rhs[i][1] = -sh[i * 16 + c]; // -Qux[i][c]
         }
-        status |= solve_quu<double, NU, 2, ASSUME_PD>(Quu, rhs, bad); // k = -Quu^-1 Qu, K[:, c] = -Quu^-1 Qux[:, c]
-        if (isx) Kp[(size_t)((t * NU + g) * NX + c) * TILE] = rhs[g == 0 ? 0 : g == 1 ? 1 : g == 2 ? 2 : 3][1];
-        if (!isx && g == 0) kp[(size_t)(t * NU + cu) * TILE] = rhs[cu][0];
+        // k = -Quu^-1 Qu, K[:, c] = -Quu^-1 Qux[:, c]
+        if (ASSUME_PD)
+            solve_quu4_fast<double>(Quu, rhs, bad);
+        else
+            status |= solve_quu<double, NU, 2, false>(Quu, rhs, bad);
         const double kg = g == 0 ? rhs[0][1] : g == 1 ? rhs[1][1] : g == 2 ? rhs[2][1] : rhs[3][1]; // K[g][c]
+        const double kc = cu == 0 ? rhs[0][0] : cu == 1 ? rhs[1][0] : cu == 2 ? rhs[2][0] : rhs[3][0]; // k[cu]
+        if (outOn) outP[(size_t)t * outS] = isx ? kg : kc;
         // Vx = Qx + K' Qu ; Vxx = Qxx + K' Qux (ilqr.py:104-105)
         double nvx = qv;
 #pragma unroll
         for (int q = 0; q < NU; ++q) nvx = fma_(rhs[q][1], Qu[q], nvx);
-        vx = isx ? nvx : 0.0;
-        TG = __builtin_amdgcn_mfma_f64_16x16x4f64(isx ? qg : 0.0, isx ? kg : 0.0, TG, 0, 0, 0);
+        vx = nvx; // (lanes c >= 12 are never asked for theirs)
+        TG = __builtin_amdgcn_mfma_f64_16x16x4f64(qg, kg, TG, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) Vt[r] = isx ? TG[r] : 0.0;
+        for (int r = 0; r < 3; ++r) Vt[r] = TG[r];
     }
     return status;
 }
@@ -1147,6 +1210,189 @@ __device__ __forceinline__ int ltv12x4_backward_sweep(const Params<float, 12, 4>
         for (int r = 0; r < 4; ++r) Vt[r] = (isx && !g3) ? TG[r] : 0.0f;
     }
     return status;
+}
+
+// ---------------------------------------------------------------- LDS staging of the n = 12 kernels
+// (the layout is described at ltv12x4_evaluate_mfma_kernel)
+constexpr int LTV_RING = 4;
+constexpr int LTV_ROWS = 80;                  // rows of a step: K 0..47, k 48..51, x 52..63, u 64..67, xref 68..79
+constexpr int LTV_CHUNK = 12 * 64 * 16;       // bytes of a step in LDS: 640 row granules, 96 of the tables, padding
+__device__ __forceinline__ void glds16(const void *src, void *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+// byte offset inside a step's LDS image of the value of problem j (0..15 of the workgroup) in row r
+__device__ __forceinline__ unsigned ltv_lds_off(int r, int j) { return (unsigned)((r * 8 + (((j >> 1) + (r >> 1)) & 7)) * 16 + (j & 1) * 8); }
+
+
+// Backward sweep of the n = 12, m = 4 model in fp64 for 16 neighbouring problems of a tile at once:
+// 16 waves, one problem each (the arithmetic of ltv12x4_backward_sweep), whose rows travel as whole
+// 128-byte lines.  Waves 0..4 fetch the 28 rows of a step (x, u, xref) and [A_t | B_t] straight into
+// an LDS ring LTV_RING steps ahead; every wave puts its gains into an LDS image of the 52 rows of
+// K_t and k_t, which waves 5..11 write out one step later, 16 bytes per lane.  (One wave per
+// workgroup, each lane loading and storing its own 8 bytes, moved 3x the bytes to HBM, as partial
+// lines, and was held to a third of the speed.)  Problems of the 16 that are not selected keep
+// their stored gains: the writing lanes skip their halves of the granules.
+constexpr int LTVB_IN = 5 * 1024;   // bytes of a step's input image: 28 rows + 96 table granules = 320 granules
+constexpr int LTVB_OUT = 7 * 1024;  // bytes of a step's output image: 52 rows = 416 granules, padded to 7 waves
+static __global__ __launch_bounds__(1024) void ltv12x4_backward_staged_kernel(Params<double, 12, 4> p) {
+    constexpr int NX = 12, NU = 4, D = LTV_RING;
+    constexpr int OFF_OUT = D * LTVB_IN, OFF_SH = OFF_OUT + 2 * LTVB_OUT, OFF_FLAG = OFF_SH + 16 * 80 * 8;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[OFF_FLAG + 64];
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nsl = slot_count(p);
+    const int slot0 = blockIdx.x * 16, slot_raw = slot0 + w;
+    const int slot = slot_raw < nsl ? slot_raw : (nsl > 0 ? nsl - 1 : 0);
+    const int o = orig_of(p, slot);
+    const bool act = slot_raw < nsl && !(p.select_converged ? (p.converged[o] == 0 || p.carried[o] == 0) : p.converged[o] != 0);
+    if (lane == 0) ((int *)(lds + OFF_FLAG))[w] = act ? 1 : 0;
+    __syncthreads();
+    unsigned actmask = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) actmask |= (unsigned)((const int *)(lds + OFF_FLAG))[j] << j;
+    if (actmask == 0) return; // uniform over the workgroup
+    const int T1 = p.N - 1;
+    const int tile = slot0 >> 6, ln0 = slot0 & 63;
+    const double *Xt = tile_ptr(p.X, tile, p.N * NX, ln0);
+    const double *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln0);
+    const double *Ut = tile_ptr(p.U, tile, T1 * NU, ln0);
+    const bool isx = c < NX;
+    const int cu = isx ? 0 : c - NX;
+    const double lw = isx ? p.Q2[c * NX + c] : p.R2[cu * NU + cu];
+    double lwd[4], lmd[3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lwd[r] = (g + 4 * r == c) ? lw : 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) lmd[r] = (g + 4 * r == c && isx) ? p.lm : 0.0;
+    // terminal condition (ilqr.py:79-82): Vx = 2 Qf (x - xref), Vxx = 2 Qf
+    double vx = isx ? p.Qf2[c * NX + c] * (Xt[(size_t)(T1 * NX + c) * TILE + w] - Rt[(size_t)(T1 * NX + c) * TILE + w]) : 0.0;
+    double Vt[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) Vt[r] = (isx && g + 4 * r == c) ? p.Qf2[c * NX + c] : 0.0;
+    // loading lanes (waves 0..4): source of this lane's granule at step 0 and its stride per step
+    const unsigned char *src = nullptr;
+    unsigned stride = 0;
+    {
+        const int q = threadIdx.x & 511, row = q >> 3, part = ((q & 7) - (row >> 1)) & 7;
+        if (q < 8 * 28) {
+            const double *b = row < 12 ? Xt + (size_t)row * TILE : row < 16 ? Ut + (size_t)(row - 12) * TILE : Rt + (size_t)(row - 16) * TILE;
+            src = (const unsigned char *)(b + 2 * part);
+            stride = (unsigned)((row >= 12 && row < 16 ? NU : NX) * TILE * sizeof(double));
+        } else {
+            const int e = q - 8 * 28 < 96 ? q - 8 * 28 : 95;
+            src = (const unsigned char *)(e < 72 ? p.ltvA + 2 * e : p.ltvB + 2 * (e - 72));
+            stride = (unsigned)((e < 72 ? NX * NX : NX * NU) * sizeof(double));
+        }
+    }
+    auto stage = [&](int t, int buf) {
+        if (w < 5) glds16(src + (size_t)t * stride, lds + buf * LTVB_IN + w * 1024);
+    };
+    // writing lanes (waves 5..11): granule j of the output image goes to row j / 8 of K_t (48 rows) or k_t
+    unsigned char *dst = nullptr;
+    unsigned dstride = 0, keep = 0, oj = 0;
+    if (w >= 5 && w < 12) {
+        const int j = (w - 5) * 64 + lane, row = j >> 3, part = ((j & 7) - (row >> 1)) & 7;
+        oj = (unsigned)j * 16;
+        if (row < 52) {
+            double *b = row < 48 ? tile_ptr(p.K, tile, T1 * NU * NX, ln0) + (size_t)row * TILE : tile_ptr(p.k, tile, T1 * NU, ln0) + (size_t)(row - 48) * TILE;
+            dst = (unsigned char *)(b + 2 * part);
+            dstride = (unsigned)((row < 48 ? NU * NX : NU) * TILE * sizeof(double));
+            keep = (actmask >> (2 * part)) & 3u; // which of the granule's two problems are written
+        }
+    }
+    auto write_out = [&](int t, int buf) {
+        if (keep == 0) return;
+        const double2 v = *(const double2 *)(lds + OFF_OUT + buf * LTVB_OUT + oj);
+        unsigned char *d = dst + (size_t)t * dstride;
+        if (keep == 3u) *(double2 *)d = v;
+        else if (keep == 1u) *(double *)d = v.x;
+        else *(double *)(d + 8) = v.y;
+    };
+    // where this lane's operands sit in a step's input image, and its gain in the output image
+    const unsigned oxu = ltv_lds_off(c, w), oxr = ltv_lds_off(16 + (isx ? c : 0), w);
+    const unsigned oF = 8 * 28 * 16 + (isx ? (g * NX + c) * 8 : NX * NX * 8 + (g * NU + cu) * 8), oFk = isx ? 4 * NX * 8 : 4 * NU * 8;
+    const unsigned ogain = ltv_lds_off(isx ? g * NX + c : 48 + cu, w);
+    const bool gain_on = isx || g == 0;
+    double *sh = (double *)(lds + OFF_SH) + w * 80;
+    bool bad = false;
+    auto one_step = [&](const unsigned char *img, unsigned char *out) {
+        const double xu_c = *(const double *)(img + oxu), xr_raw = *(const double *)(img + oxr);
+        const double F0 = *(const double *)(img + oF), F1 = *(const double *)(img + oF + oFk), F2 = *(const double *)(img + oF + 2 * oFk);
+        const double xr_c = isx ? xr_raw : 0.0;
+        // first-order terms: [Qx; Qu] = [lx; lu] + F' Vx (ilqr.py:93-94)
+        double part = F0 * __shfl(vx, g) + F1 * __shfl(vx, g + 4) + F2 * __shfl(vx, g + 8);
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        const double qv = fma_(lw, xu_c - xr_c, part);
+        // W = (Vxx + lm I) F, G = F' W in both layouts (see ltv12x4_backward_sweep)
+        v4f64_ W = {0.0, 0.0, 0.0, 0.0};
+        W = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[0] + lmd[0], F0, W, 0, 0, 0);
+        W = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[1] + lmd[1], F1, W, 0, 0, 0);
+        W = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[2] + lmd[2], F2, W, 0, 0, 0);
+        v4f64_ TG = {0.0, 0.0, 0.0, 0.0}, DG = {0.0, 0.0, 0.0, 0.0};
+        TG = __builtin_amdgcn_mfma_f64_16x16x4f64(W[0], F0, TG, 0, 0, 0);
+        TG = __builtin_amdgcn_mfma_f64_16x16x4f64(W[1], F1, TG, 0, 0, 0);
+        TG = __builtin_amdgcn_mfma_f64_16x16x4f64(W[2], F2, TG, 0, 0, 0);
+        DG = __builtin_amdgcn_mfma_f64_16x16x4f64(F0, W[0], DG, 0, 0, 0);
+        DG = __builtin_amdgcn_mfma_f64_16x16x4f64(F1, W[1], DG, 0, 0, 0);
+        DG = __builtin_amdgcn_mfma_f64_16x16x4f64(F2, W[2], DG, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) TG[r] += lwd[r];
+        const double qg = DG[3] + lwd[3]; // Qux[g][c] (c < 12), Quu[g][c - 12] (c >= 12)
+        // exchange through the wave's own LDS words: a wave's LDS accesses execute in order
+        sh[g * 16 + c] = qg;
+        if (g == 0) sh[64 + c] = qv;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double Quu[NU][NU], rhs[NU][2], Qu[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) Quu[i][j] = sh[i * 16 + NX + j];
+            Qu[i] = sh[64 + NX + i];
+            rhs[i][0] = -Qu[i];
+            rhs[i][1] = -sh[i * 16 + c]; // -Qux[i][c]
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        solve_quu4_fast<double>(Quu, rhs, bad); // k = -Quu^-1 Qu, K[:, c] = -Quu^-1 Qux[:, c]
+        const double kg = g == 0 ? rhs[0][1] : g == 1 ? rhs[1][1] : g == 2 ? rhs[2][1] : rhs[3][1]; // K[g][c]
+        const double kc = cu == 0 ? rhs[0][0] : cu == 1 ? rhs[1][0] : cu == 2 ? rhs[2][0] : rhs[3][0]; // k[cu]
+        if (gain_on) *(double *)(out + ogain) = isx ? kg : kc;
+        // Vx = Qx + K' Qu ; Vxx = Qxx + K' Qux (ilqr.py:104-105)
+        double nvx = qv;
+#pragma unroll
+        for (int q = 0; q < NU; ++q) nvx = fma_(rhs[q][1], Qu[q], nvx);
+        vx = nvx;
+        TG = __builtin_amdgcn_mfma_f64_16x16x4f64(qg, kg, TG, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Vt[r] = TG[r];
+    };
+    // Iteration i handles step t = T1 - 1 - i from ring slot i mod D and leaves its gains in output
+    // image i mod 2.  Per iteration: wait until this wave's piece of step t has landed, meet (every
+    // piece has landed; every wave is done with the previous step, its gains are in the image),
+    // refill the ring slot and write out the image of the previous step, compute.
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s) stage(T1 - 1 - s > 0 ? T1 - 1 - s : 0, s);
+    for (int ib = 0; ib < T1; ib += D) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            const int i = ib + s, t = T1 - 1 - i;
+            if (t < 0) break; // uniform over the workgroup
+            if (w < 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 2) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage(t - (D - 1) > 0 ? t - (D - 1) : 0, (s + D - 1) % D);
+            if (i > 0) write_out(t + 1, (s + 1) & 1);
+            if (act) one_step(lds + s * LTVB_IN, lds + OFF_OUT + (s & 1) * LTVB_OUT);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    write_out(0, (T1 - 1) & 1);
+    if (act && lane == 0) p.redo[o] = bad ? 1 : 0;
 }
 
 // REDO = false: every selected problem, branch-free solve; a problem whose Quu was not positive
@@ -1792,27 +2038,34 @@ __global__ __launch_bounds__(64) void evaluate_listed_kernel(Params<T, M::NX, M:
 // a candidate are summed at the end.  Sums run in the matrix unit's order: costs and the accepted
 // step agree with the lane-per-candidate kernel to rounding, not bit for bit.
 //
-// A workgroup is 16 waves = 16 neighbouring problems of a tile, kept in step by a barrier every
-// few time steps: the 16 waves read their 8-byte pieces of the same 128-byte line within the same
-// step, so every line is fetched from HBM once (free-running waves drift apart over the horizon
-// and re-fetch the lines: 6x the traffic, measured).
+// A workgroup is 16 waves = 16 neighbouring problems of a tile.  A problem's share of a row is 8
+// bytes of a 128-byte line that the 16 problems share, and a wave that loads its own operands
+// touches 16 to 64 lines per load instruction, which the texture-address unit works through one
+// line at a time (measured: the kernel ran at the speed of that unit, not of the matrix unit or of
+// HBM).  So the workgroup fetches the 80 rows of a time step (K, k, x, u, xref: one 128-byte line
+// each for its 16 problems) and that step's [A_t | B_t] (shared by all problems) as whole lines
+// straight into LDS (12 wave instructions of 1 KiB per step instead of 240 scattered ones), LTV_RING
+// steps ahead, and every wave takes its operands from there.
+//
+// LDS image of one step: 16-byte granules in the order the loading lanes hold them (the direct
+// load writes lane i of a wave at base + 16 i).  Granule 8 r + j of row r holds the problems
+// 2 P, 2 P + 1 with P = (j - r / 2) mod 8: a wave reads the same problem of 16 different rows in
+// one instruction, and the rotation puts those 16 on 16 different bank groups.
 static __global__ __launch_bounds__(1024) void ltv12x4_evaluate_mfma_kernel(Params<double, 12, 4> p) {
-    constexpr int NX = 12, NU = 4;
+    constexpr int NX = 12, NU = 4, D = LTV_RING;
+    __shared__ __attribute__((aligned(16))) unsigned char ring[D * LTV_CHUNK];
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave = problem of the workgroup
     const int nsl = slot_count(p);
-    const int slot_raw = blockIdx.x * 16 + (threadIdx.x >> 6);
+    const int slot0 = blockIdx.x * 16, slot_raw = slot0 + w;
     const int slot = slot_raw < nsl ? slot_raw : (nsl > 0 ? nsl - 1 : 0);
     const int o = orig_of(p, slot);
     const bool act = slot_raw < nsl && p.converged[o] == 0;
     if (!__syncthreads_or(act)) return; // no wave of this workgroup has work
     const int T1 = p.N - 1;
-    const int tile = slot >> 6, ln = slot & 63;
-    const double *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
-    const double *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
-    const double *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
-    const double *kp = tile_ptr(p.k, tile, T1 * NU, ln);
-    const double *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
-    const double Jcur = p.J[o];
+    const int tile = slot0 >> 6, ln0 = slot0 & 63; // the workgroup's 16 problems: lanes ln0 .. ln0 + 15 of one tile
+    const double *Xt = tile_ptr(p.X, tile, p.N * NX, ln0);
+    const double *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln0);
     const double alpha = pow2_neg<double>(c);
     double qw[3], qfw[3];
 #pragma unroll
@@ -1821,67 +2074,105 @@ static __global__ __launch_bounds__(1024) void ltv12x4_evaluate_mfma_kernel(Para
         qfw[r] = p.Qf[(g + 4 * r) * NX + g + 4 * r];
     }
     const double rw = p.R[g * NU + g], lo = p.lo[g], hi = p.hi[g];
-    struct Row {
-        double xp[3], xr[3], up, kf, Kop[3], Fop[4];
-    };
-    auto load_row = [&](int t, Row &r) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            r.xp[q] = Xt[(size_t)(t * NX + g + 4 * q) * TILE];
-            r.xr[q] = Rt[(size_t)(t * NX + g + 4 * q) * TILE];
-            r.Kop[q] = c < NU ? Kp[(size_t)((t * NU + c) * NX + g + 4 * q) * TILE] : 0.0;   // K[c][g + 4q]
-            r.Fop[q] = c < NX ? p.ltvA[(size_t)t * NX * NX + c * NX + g + 4 * q] : 0.0;      // A_t[c][g + 4q]
-        }
-        r.Fop[3] = c < NX ? p.ltvB[(size_t)t * NX * NU + c * NU + g] : 0.0;                   // B_t[c][g]
-        r.up = Ut[(size_t)(t * NU + g) * TILE];
-        r.kf = kp[(size_t)(t * NU + g) * TILE];
-    };
+    // candidates start from the stored first state
     double z[4], cost = 0.0;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) z[r] = Xt[(size_t)(g + 4 * r) * TILE];
+    for (int r = 0; r < 3; ++r) z[r] = Xt[(size_t)(g + 4 * r) * TILE + w];
     z[3] = 0.0;
-    Row nxt;
-    load_row(0, nxt);
-    for (int t = 0; t < T1; ++t) {
-        if ((t & (LTV_SYNC_EVERY - 1)) == 0) __syncthreads();
-        if (!act) continue; // wave-uniform
-        const Row r = nxt;
-        load_row(t + 1 < T1 ? t + 1 : t, nxt);
+    // this lane's granule of every step: source address at step 0 and its stride per step
+    const unsigned char *src;
+    unsigned stride;
+    {
+        const int q = threadIdx.x, row = q >> 3, part = ((q & 7) - (row >> 1)) & 7;
+        if (q < 8 * LTV_ROWS) {
+            const double *b;
+            int r, rows;
+            if (row < 48) b = tile_ptr(p.K, tile, T1 * NU * NX, ln0), r = row, rows = NU * NX;
+            else if (row < 52) b = tile_ptr(p.k, tile, T1 * NU, ln0), r = row - 48, rows = NU;
+            else if (row < 64) b = Xt, r = row - 52, rows = NX;
+            else if (row < 68) b = tile_ptr(p.U, tile, T1 * NU, ln0), r = row - 64, rows = NU;
+            else b = Rt, r = row - 68, rows = NX;
+            src = (const unsigned char *)(b + (size_t)r * TILE + 2 * part);
+            stride = (unsigned)(rows * TILE * sizeof(double));
+        } else {
+            const int e = q - 8 * LTV_ROWS < 96 ? q - 8 * LTV_ROWS : 95; // 72 granules of A_t, 24 of B_t (the padding repeats the last)
+            src = (const unsigned char *)(e < 72 ? p.ltvA + 2 * e : p.ltvB + 2 * (e - 72));
+            stride = (unsigned)((e < 72 ? NX * NX : NX * NU) * sizeof(double));
+        }
+    }
+    auto stage = [&](int t, int buf) {
+        if (w < 12) glds16(src + (size_t)t * stride, ring + buf * LTV_CHUNK + w * 1024);
+    };
+    // where this lane's operands sit in a step's image.  The matrix instruction's left operand of
+    // lane (c, g) is row c of the left factor: rows >= 4 of K and rows >= 12 of [A_t | B_t] only
+    // produce result rows nobody reads, so those lanes simply read a valid row.
+    unsigned oxp[3], oxr[3], oK[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        oxp[q] = ltv_lds_off(52 + g + 4 * q, w);
+        oxr[q] = ltv_lds_off(68 + g + 4 * q, w);
+        oK[q] = ltv_lds_off((c & 3) * NX + g + 4 * q, w);
+    }
+    const unsigned oup = ltv_lds_off(64 + g, w), okf = ltv_lds_off(48 + g, w);
+    const int cc = c < NX ? c : 0;
+    const unsigned oA = 8 * LTV_ROWS * 16 + (cc * NX + g) * 8, oB = 8 * LTV_ROWS * 16 + NX * NX * 8 + (cc * NU + g) * 8;
+    auto one_step = [&](const unsigned char *img) {
+        auto at = [&](unsigned off) { return *(const double *)(img + off); };
         double dx[3], e[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            dx[q] = z[q] - r.xp[q];
-            e[q] = z[q] - r.xr[q];
+            dx[q] = z[q] - at(oxp[q]);
+            e[q] = z[q] - at(oxr[q]);
         }
         v4f64_ KD = {0.0, 0.0, 0.0, 0.0};
-        KD = __builtin_amdgcn_mfma_f64_16x16x4f64(r.Kop[0], dx[0], KD, 0, 0, 0);
-        KD = __builtin_amdgcn_mfma_f64_16x16x4f64(r.Kop[1], dx[1], KD, 0, 0, 0);
-        KD = __builtin_amdgcn_mfma_f64_16x16x4f64(r.Kop[2], dx[2], KD, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) KD = __builtin_amdgcn_mfma_f64_16x16x4f64(at(oK[q]), dx[q], KD, 0, 0, 0);
         // u_new = (u_prev + alpha k) + K (x_new - x_prev), clamped (ilqr.py:56-61)
-        double v = fma_(alpha, r.kf, r.up) + KD[0];
+        double v = fma_(alpha, at(okf), at(oup)) + KD[0];
         v = (lo > v) ? lo : v;
         v = (hi < v) ? hi : v;
         z[3] = v;
-        double stage = (qw[0] * e[0]) * e[0];
-        stage = fma_(qw[1] * e[1], e[1], stage);
-        stage = fma_(qw[2] * e[2], e[2], stage);
-        stage = fma_(rw * v, v, stage);
-        cost += stage;
+        double stage_cost = (qw[0] * e[0]) * e[0];
+        stage_cost = fma_(qw[1] * e[1], e[1], stage_cost);
+        stage_cost = fma_(qw[2] * e[2], e[2], stage_cost);
+        stage_cost = fma_(rw * v, v, stage_cost);
+        cost += stage_cost;
         v4f64_ Xn = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Xn = __builtin_amdgcn_mfma_f64_16x16x4f64(r.Fop[q], z[q], Xn, 0, 0, 0);
+        for (int q = 0; q < 3; ++q) Xn = __builtin_amdgcn_mfma_f64_16x16x4f64(at(oA + 32 * q), z[q], Xn, 0, 0, 0);
+        Xn = __builtin_amdgcn_mfma_f64_16x16x4f64(at(oB), z[3], Xn, 0, 0, 0);
 #pragma unroll
         for (int q = 0; q < 3; ++q) z[q] = Xn[q];
+    };
+    // Step t is computed from ring slot t mod D while the steps t + 1 .. t + D - 1 are on their way.
+    // A direct load is ordered before a read of its data only by the loading wave's counted wait
+    // followed by a barrier, so per step: wait until this wave's piece of step t has landed, meet
+    // (every piece has landed, and every wave is done with step t - 1), refill the slot step t - 1
+    // used, compute.
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s) stage(s < T1 ? s : T1 - 1, s);
+    for (int tb = 0; tb < T1; tb += D) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            const int t = tb + s;
+            if (t >= T1) break; // uniform over the workgroup
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 2) : "memory");
+            __builtin_amdgcn_s_barrier();
+            stage(t + D - 1 < T1 ? t + D - 1 : T1 - 1, (s + D - 1) % D);
+            if (act) one_step(ring + s * LTV_CHUNK);
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     {   // terminal term (ilqr.py:44-45)
         double term = 0.0;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            const double e = z[q] - Rt[(size_t)(T1 * NX + g + 4 * q) * TILE];
+            const double e = z[q] - Rt[(size_t)(T1 * NX + g + 4 * q) * TILE + w];
             term = fma_(qfw[q] * e, e, term);
         }
         cost += term;
     }
+    const double Jcur = p.J[o];
     cost += __shfl_xor(cost, 16);
     cost += __shfl_xor(cost, 32);
     // lowest step index whose cost improves strictly (ilqr.py:65; NaN never passes)
