@@ -288,13 +288,8 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
             static const bool generic = getenv("ILQR_LTV_GENERIC") != nullptr;
             if (mode == 0 && !generic) {
                 auto p = make_params<T, NX, NU>(c);
-                const int tiles = (c.count + 63) / 64;
-                const int blocks = ((tiles + 7) / 8) * 8 * 64;
-                if constexpr (std::is_same<T, double>::value)
-                    hipLaunchKernelGGL(ltv12x4_backward_staged_kernel, dim3((c.count + 15) / 16), dim3(1024), 0, s, p);
-                else
-                    hipLaunchKernelGGL((ltv12x4_backward_mfma_kernel<T, false>), dim3(blocks), dim3(64), 0, s, p);
-                hipLaunchKernelGGL((ltv12x4_backward_mfma_kernel<T, true>), dim3(blocks), dim3(64), 0, s, p);
+                hipLaunchKernelGGL(ltv12x4_backward_staged_kernel<T>, dim3((c.count + 15) / 16), dim3(1024), 0, s, p);
+                hipLaunchKernelGGL(ltv12x4_backward_redo_kernel<T>, dim3(c.count), dim3(64), 0, s, p);
                 return hipGetLastError();
             }
         }
@@ -436,10 +431,7 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
             if (!barrier_on(c) && c.n_alphas <= 16 && !generic) {
                 if (!(c.eval_stages & 1)) return hipSuccess;
                 auto p = make_params<T, NX, NU>(c);
-                if constexpr (std::is_same<T, double>::value)
-                    hipLaunchKernelGGL(ltv12x4_evaluate_mfma_kernel, dim3((c.count + 15) / 16), dim3(1024), 0, s, p);
-                else
-                    hipLaunchKernelGGL(ltv12x4_evaluate_mfma_f32_kernel, dim3((c.count + 15) / 16), dim3(1024), 0, s, p);
+                hipLaunchKernelGGL(ltv12x4_evaluate_mfma_kernel<T>, dim3((c.count + 15) / 16), dim3(1024), 0, s, p);
                 return hipGetLastError();
             }
         }

@@ -934,7 +934,10 @@ __device__ __forceinline__ double fast_rcp(double d) {
     r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
     return r;
 }
-__device__ __forceinline__ float fast_rcp(float d) { return 1.0f / d; }
+__device__ __forceinline__ float fast_rcp(float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+}
 
 // Branch-free L D L' solve of the 4 x 4 system Quu [k | K_c] = rhs for the matrix-unit kernels
 // (same elimination order as solve_quu, reciprocals by fast_rcp); `bad` if a pivot is not positive.
@@ -1215,31 +1218,63 @@ __device__ __forceinline__ int ltv12x4_backward_sweep(const Params<float, 12, 4>
 // ---------------------------------------------------------------- LDS staging of the n = 12 kernels
 // (the layout is described at ltv12x4_evaluate_mfma_kernel)
 constexpr int LTV_RING = 4;
-constexpr int LTV_ROWS = 80;                  // rows of a step: K 0..47, k 48..51, x 52..63, u 64..67, xref 68..79
-constexpr int LTV_CHUNK = 12 * 64 * 16;       // bytes of a step in LDS: 640 row granules, 96 of the tables, padding
 __device__ __forceinline__ void glds16(const void *src, void *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
-// byte offset inside a step's LDS image of the value of problem j (0..15 of the workgroup) in row r
-__device__ __forceinline__ unsigned ltv_lds_off(int r, int j) { return (unsigned)((r * 8 + (((j >> 1) + (r >> 1)) & 7)) * 16 + (j & 1) * 8); }
+// Geometry of a staged row: the values of the workgroup's 16 problems are 16 / PPG granules of 16
+// bytes (PPG problems each).  Granule GPR r + j of row r holds the problems PPG P .. PPG P + PPG - 1
+// with P = (j - rot(r)) mod GPR, rot(r) = r GPR / 16.
+template <typename T> struct LtvStage {
+    static constexpr int PPG = 16 / (int)sizeof(T), GPR = 16 / PPG;
+    static __device__ __forceinline__ int rot(int r) { return (r * GPR) >> 4; }
+    // which problems granule q (in loading order) of a run of rows holds: first problem of the granule
+    static __device__ __forceinline__ int first_problem(int q) { return PPG * (((q % GPR) - rot(q / GPR)) & (GPR - 1)); }
+    // byte offset inside a step's LDS image of the value of problem j (0..15 of the workgroup) in row r
+    static __device__ __forceinline__ unsigned off(int r, int j) {
+        return (unsigned)((r * GPR + (((j / PPG) + rot(r)) & (GPR - 1))) * 16 + (j % PPG) * (int)sizeof(T));
+    }
+};
+// The 16 x 16 x 4 matrix instruction of either precision.  Lane (c, g) supplies left[c][k] and
+// right[k][c] with k = g; register r of its result holds row g + 4 r (fp64) or 4 g + r (fp32) of
+// column c.  The kernels below are written for the fp64 association "register r of lane group g
+// is row g + 4 r"; in fp32 they get it by giving lane c the role of index tau(c) = c / 4 + 4 (c % 4)
+// wherever a lane stands for a row or a column of a matrix (hardware row 4 g + r then is index
+// tau(4 g + r) = g + 4 r; tau is its own inverse).
+template <typename T> struct Mfma4;
+template <> struct Mfma4<double> {
+    using acc = v4f64_;
+    static __device__ __forceinline__ acc run(double a, double b, acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int tau(int c) { return c; }
+};
+template <> struct Mfma4<float> {
+    using acc = v4f32_;
+    static __device__ __forceinline__ acc run(float a, float b, acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int tau(int c) { return (c >> 2) + 4 * (c & 3); }
+};
 
-
-// Backward sweep of the n = 12, m = 4 model in fp64 for 16 neighbouring problems of a tile at once:
-// 16 waves, one problem each (the arithmetic of ltv12x4_backward_sweep), whose rows travel as whole
-// 128-byte lines.  Waves 0..4 fetch the 28 rows of a step (x, u, xref) and [A_t | B_t] straight into
-// an LDS ring LTV_RING steps ahead; every wave puts its gains into an LDS image of the 52 rows of
-// K_t and k_t, which waves 5..11 write out one step later, 16 bytes per lane.  (One wave per
-// workgroup, each lane loading and storing its own 8 bytes, moved 3x the bytes to HBM, as partial
-// lines, and was held to a third of the speed.)  Problems of the 16 that are not selected keep
-// their stored gains: the writing lanes skip their halves of the granules.
-constexpr int LTVB_IN = 5 * 1024;   // bytes of a step's input image: 28 rows + 96 table granules = 320 granules
-constexpr int LTVB_OUT = 7 * 1024;  // bytes of a step's output image: 52 rows = 416 granules, padded to 7 waves
-static __global__ __launch_bounds__(1024) void ltv12x4_backward_staged_kernel(Params<double, 12, 4> p) {
-    constexpr int NX = 12, NU = 4, D = LTV_RING;
-    constexpr int OFF_OUT = D * LTVB_IN, OFF_SH = OFF_OUT + 2 * LTVB_OUT, OFF_FLAG = OFF_SH + 16 * 80 * 8;
+// Backward sweep of the n = 12, m = 4 model for 16 neighbouring problems of a tile at once: 16
+// waves, one problem each (the arithmetic of ltv12x4_backward_sweep with the branch-free solve),
+// whose rows travel as whole lines.  The first waves fetch the 28 rows of a step (x, u, xref) and
+// [A_t | B_t] straight into an LDS ring LTV_RING steps ahead; every wave puts its gains into an LDS
+// image of the 52 rows of K_t and k_t, which the next waves write out one step later, 16 bytes per
+// lane.  (One wave per workgroup, each lane loading and storing its own 8 bytes, moved 3x the bytes
+// to HBM, as partial lines, and was held to a third of the speed.)  Problems of the 16 that are not
+// selected keep their stored gains: the writing lanes skip their parts of the granules.  A problem
+// whose Quu was not positive definite somewhere is flagged in p.redo for the fallback launch.
+template <typename T> __global__ __launch_bounds__(1024) void ltv12x4_backward_staged_kernel(Params<T, 12, 4> p) {
+    using St = LtvStage<T>;
+    using MF = Mfma4<T>;
+    using acc = typename MF::acc;
+    constexpr int NX = 12, NU = 4, D = LTV_RING, ES = (int)sizeof(T), GPR = St::GPR, PPG = St::PPG;
+    constexpr int IN_ROWS = 28, OUT_ROWS = 52, AGR = NX * NX * ES / 16, TBL = NX * (NX + NU) * ES / 16;
+    constexpr int NLOAD = (IN_ROWS * GPR + TBL + 63) / 64, NSTORE = (OUT_ROWS * GPR + 63) / 64; // waves that load / that store
+    constexpr int IN_BYTES = NLOAD * 1024, OUT_BYTES = NSTORE * 1024;
+    constexpr int OFF_OUT = D * IN_BYTES, OFF_SH = OFF_OUT + 2 * OUT_BYTES, OFF_FLAG = OFF_SH + 16 * 80 * ES;
+    static_assert(NLOAD + NSTORE <= 16, "wave roles");
     __shared__ __attribute__((aligned(16))) unsigned char lds[OFF_FLAG + 64];
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int ci = MF::tau(c); // the row / column of the 16 x 16 tiles this lane stands for
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nsl = slot_count(p);
     const int slot0 = blockIdx.x * 16, slot_raw = slot0 + w;
@@ -1254,126 +1289,139 @@ static __global__ __launch_bounds__(1024) void ltv12x4_backward_staged_kernel(Pa
     if (actmask == 0) return; // uniform over the workgroup
     const int T1 = p.N - 1;
     const int tile = slot0 >> 6, ln0 = slot0 & 63;
-    const double *Xt = tile_ptr(p.X, tile, p.N * NX, ln0);
-    const double *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln0);
-    const double *Ut = tile_ptr(p.U, tile, T1 * NU, ln0);
-    const bool isx = c < NX;
-    const int cu = isx ? 0 : c - NX;
-    const double lw = isx ? p.Q2[c * NX + c] : p.R2[cu * NU + cu];
-    double lwd[4], lmd[3];
+    const T *Xt = tile_ptr(p.X, tile, p.N * NX, ln0);
+    const T *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln0);
+    const T *Ut = tile_ptr(p.U, tile, T1 * NU, ln0);
+    const bool isx = ci < NX;
+    const int cu = isx ? 0 : ci - NX;
+    // per-lane constants: weight of this lane's component of [x; u], the diagonal terms it adds to
+    // its registers of the tiles
+    const T lw = isx ? p.Q2[ci * NX + ci] : p.R2[cu * NU + cu];
+    T lwd[4], lmd[3];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) lwd[r] = (g + 4 * r == c) ? lw : 0.0;
+    for (int r = 0; r < 4; ++r) lwd[r] = (g + 4 * r == ci) ? lw : T(0);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) lmd[r] = (g + 4 * r == c && isx) ? p.lm : 0.0;
+    for (int r = 0; r < 3; ++r) lmd[r] = (g + 4 * r == ci && isx) ? p.lm : T(0);
     // terminal condition (ilqr.py:79-82): Vx = 2 Qf (x - xref), Vxx = 2 Qf
-    double vx = isx ? p.Qf2[c * NX + c] * (Xt[(size_t)(T1 * NX + c) * TILE + w] - Rt[(size_t)(T1 * NX + c) * TILE + w]) : 0.0;
-    double Vt[3];
+    T vx = isx ? p.Qf2[ci * NX + ci] * (Xt[(size_t)(T1 * NX + ci) * TILE + w] - Rt[(size_t)(T1 * NX + ci) * TILE + w]) : T(0);
+    T Vt[3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) Vt[r] = (isx && g + 4 * r == c) ? p.Qf2[c * NX + c] : 0.0;
-    // loading lanes (waves 0..4): source of this lane's granule at step 0 and its stride per step
+    for (int r = 0; r < 3; ++r) Vt[r] = (isx && g + 4 * r == ci) ? p.Qf2[ci * NX + ci] : T(0);
+    // loading lanes: source of this lane's granule at step 0 and its stride per step
     const unsigned char *src = nullptr;
     unsigned stride = 0;
     {
-        const int q = threadIdx.x & 511, row = q >> 3, part = ((q & 7) - (row >> 1)) & 7;
-        if (q < 8 * 28) {
-            const double *b = row < 12 ? Xt + (size_t)row * TILE : row < 16 ? Ut + (size_t)(row - 12) * TILE : Rt + (size_t)(row - 16) * TILE;
-            src = (const unsigned char *)(b + 2 * part);
-            stride = (unsigned)((row >= 12 && row < 16 ? NU : NX) * TILE * sizeof(double));
+        const int q = threadIdx.x, row = q / GPR;
+        if (q < IN_ROWS * GPR) {
+            const T *b = row < 12 ? Xt + (size_t)row * TILE : row < 16 ? Ut + (size_t)(row - 12) * TILE : Rt + (size_t)(row - 16) * TILE;
+            src = (const unsigned char *)(b + St::first_problem(q));
+            stride = (unsigned)((row >= 12 && row < 16 ? NU : NX) * TILE * ES);
         } else {
-            const int e = q - 8 * 28 < 96 ? q - 8 * 28 : 95;
-            src = (const unsigned char *)(e < 72 ? p.ltvA + 2 * e : p.ltvB + 2 * (e - 72));
-            stride = (unsigned)((e < 72 ? NX * NX : NX * NU) * sizeof(double));
+            const int e = q - IN_ROWS * GPR < TBL ? q - IN_ROWS * GPR : TBL - 1; // (padding lanes repeat the last granule)
+            src = (const unsigned char *)(e < AGR ? p.ltvA + PPG * e : p.ltvB + PPG * (e - AGR));
+            stride = (unsigned)((e < AGR ? NX * NX : NX * NU) * ES);
         }
     }
     auto stage = [&](int t, int buf) {
-        if (w < 5) glds16(src + (size_t)t * stride, lds + buf * LTVB_IN + w * 1024);
+        if (w < NLOAD) glds16(src + (size_t)t * stride, lds + buf * IN_BYTES + w * 1024);
     };
-    // writing lanes (waves 5..11): granule j of the output image goes to row j / 8 of K_t (48 rows) or k_t
+    // writing lanes: granule j of the output image goes to row j / GPR of K_t (48 rows) or k_t
     unsigned char *dst = nullptr;
     unsigned dstride = 0, keep = 0, oj = 0;
-    if (w >= 5 && w < 12) {
-        const int j = (w - 5) * 64 + lane, row = j >> 3, part = ((j & 7) - (row >> 1)) & 7;
+    if (w >= NLOAD && w < NLOAD + NSTORE) {
+        const int j = (w - NLOAD) * 64 + lane, row = j / GPR;
         oj = (unsigned)j * 16;
-        if (row < 52) {
-            double *b = row < 48 ? tile_ptr(p.K, tile, T1 * NU * NX, ln0) + (size_t)row * TILE : tile_ptr(p.k, tile, T1 * NU, ln0) + (size_t)(row - 48) * TILE;
-            dst = (unsigned char *)(b + 2 * part);
-            dstride = (unsigned)((row < 48 ? NU * NX : NU) * TILE * sizeof(double));
-            keep = (actmask >> (2 * part)) & 3u; // which of the granule's two problems are written
+        if (row < OUT_ROWS) {
+            T *b = row < 48 ? tile_ptr(p.K, tile, T1 * NU * NX, ln0) + (size_t)row * TILE : tile_ptr(p.k, tile, T1 * NU, ln0) + (size_t)(row - 48) * TILE;
+            const int fp = St::first_problem(j);
+            dst = (unsigned char *)(b + fp);
+            dstride = (unsigned)((row < 48 ? NU * NX : NU) * TILE * ES);
+            keep = (actmask >> fp) & ((1u << PPG) - 1u); // which of the granule's problems are written
         }
     }
     auto write_out = [&](int t, int buf) {
         if (keep == 0) return;
-        const double2 v = *(const double2 *)(lds + OFF_OUT + buf * LTVB_OUT + oj);
+        const uint4 v = *(const uint4 *)(lds + OFF_OUT + buf * OUT_BYTES + oj);
         unsigned char *d = dst + (size_t)t * dstride;
-        if (keep == 3u) *(double2 *)d = v;
-        else if (keep == 1u) *(double *)d = v.x;
-        else *(double *)(d + 8) = v.y;
+        if (keep == (1u << PPG) - 1u) {
+            *(uint4 *)d = v;
+        } else {
+            T e[PPG];
+            __builtin_memcpy(e, &v, 16);
+#pragma unroll
+            for (int q = 0; q < PPG; ++q)
+                if ((keep >> q) & 1u) ((T *)d)[q] = e[q];
+        }
     };
     // where this lane's operands sit in a step's input image, and its gain in the output image
-    const unsigned oxu = ltv_lds_off(c, w), oxr = ltv_lds_off(16 + (isx ? c : 0), w);
-    const unsigned oF = 8 * 28 * 16 + (isx ? (g * NX + c) * 8 : NX * NX * 8 + (g * NU + cu) * 8), oFk = isx ? 4 * NX * 8 : 4 * NU * 8;
-    const unsigned ogain = ltv_lds_off(isx ? g * NX + c : 48 + cu, w);
+    const unsigned oxu = St::off(ci, w), oxr = St::off(16 + (isx ? ci : 0), w);
+    const unsigned oF = IN_ROWS * GPR * 16 + (isx ? (g * NX + ci) * ES : NX * NX * ES + (g * NU + cu) * ES), oFk = isx ? 4 * NX * ES : 4 * NU * ES;
+    const unsigned ogain = St::off(isx ? g * NX + ci : 48 + cu, w);
     const bool gain_on = isx || g == 0;
-    double *sh = (double *)(lds + OFF_SH) + w * 80;
+    T *sh = (T *)(lds + OFF_SH) + w * 80;
     bool bad = false;
     auto one_step = [&](const unsigned char *img, unsigned char *out) {
-        const double xu_c = *(const double *)(img + oxu), xr_raw = *(const double *)(img + oxr);
-        const double F0 = *(const double *)(img + oF), F1 = *(const double *)(img + oF + oFk), F2 = *(const double *)(img + oF + 2 * oFk);
-        const double xr_c = isx ? xr_raw : 0.0;
+        const T xu_c = *(const T *)(img + oxu), xr_raw = *(const T *)(img + oxr);
+        const T F0 = *(const T *)(img + oF), F1 = *(const T *)(img + oF + oFk), F2 = *(const T *)(img + oF + 2 * oFk); // F[g + 4 kk][ci]
+        const T xr_c = isx ? xr_raw : T(0);
         // first-order terms: [Qx; Qu] = [lx; lu] + F' Vx (ilqr.py:93-94)
-        double part = F0 * __shfl(vx, g) + F1 * __shfl(vx, g + 4) + F2 * __shfl(vx, g + 8);
+        T part = F0 * __shfl(vx, MF::tau(g)) + F1 * __shfl(vx, MF::tau(g + 4)) + F2 * __shfl(vx, MF::tau(g + 8));
         part += __shfl_xor(part, 16);
         part += __shfl_xor(part, 32);
-        const double qv = fma_(lw, xu_c - xr_c, part);
-        // W = (Vxx + lm I) F, G = F' W in both layouts (see ltv12x4_backward_sweep)
-        v4f64_ W = {0.0, 0.0, 0.0, 0.0};
-        W = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[0] + lmd[0], F0, W, 0, 0, 0);
-        W = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[1] + lmd[1], F1, W, 0, 0, 0);
-        W = __builtin_amdgcn_mfma_f64_16x16x4f64(Vt[2] + lmd[2], F2, W, 0, 0, 0);
-        v4f64_ TG = {0.0, 0.0, 0.0, 0.0}, DG = {0.0, 0.0, 0.0, 0.0};
-        TG = __builtin_amdgcn_mfma_f64_16x16x4f64(W[0], F0, TG, 0, 0, 0);
-        TG = __builtin_amdgcn_mfma_f64_16x16x4f64(W[1], F1, TG, 0, 0, 0);
-        TG = __builtin_amdgcn_mfma_f64_16x16x4f64(W[2], F2, TG, 0, 0, 0);
-        DG = __builtin_amdgcn_mfma_f64_16x16x4f64(F0, W[0], DG, 0, 0, 0);
-        DG = __builtin_amdgcn_mfma_f64_16x16x4f64(F1, W[1], DG, 0, 0, 0);
-        DG = __builtin_amdgcn_mfma_f64_16x16x4f64(F2, W[2], DG, 0, 0, 0);
+        const T qv = fma_(lw, xu_c - xr_c, part);
+        // W = (Vxx + lm I) F, G = F' W in both layouts (see ltv12x4_backward_sweep).  Lanes that stand
+        // for an input hold rows 12..15 of the left factor, which only produce rows of the result that
+        // no later product reads: they need no masking anywhere below.
+        acc W = {T(0), T(0), T(0), T(0)};
+        W = MF::run(Vt[0] + lmd[0], F0, W);
+        W = MF::run(Vt[1] + lmd[1], F1, W);
+        W = MF::run(Vt[2] + lmd[2], F2, W);
+        acc TG = {T(0), T(0), T(0), T(0)}, DG = {T(0), T(0), T(0), T(0)};
+        TG = MF::run(W[0], F0, TG);
+        TG = MF::run(W[1], F1, TG);
+        TG = MF::run(W[2], F2, TG);
+        DG = MF::run(F0, W[0], DG);
+        DG = MF::run(F1, W[1], DG);
+        DG = MF::run(F2, W[2], DG);
+        // + lxx = 2Q, luu = 2R on the diagonal (ilqr.py:91-92)
 #pragma unroll
         for (int r = 0; r < 4; ++r) TG[r] += lwd[r];
-        const double qg = DG[3] + lwd[3]; // Qux[g][c] (c < 12), Quu[g][c - 12] (c >= 12)
+        const T qg = DG[3] + lwd[3]; // Qux[g][ci] (ci < 12), Quu[g][ci - 12] (ci >= 12)
         // exchange through the wave's own LDS words: a wave's LDS accesses execute in order
-        sh[g * 16 + c] = qg;
-        if (g == 0) sh[64 + c] = qv;
+        sh[g * 16 + ci] = qg;
+        if (g == 0) sh[64 + ci] = qv;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        double Quu[NU][NU], rhs[NU][2], Qu[NU];
+        T Quu[NU][NU], rhs[NU][2], Qu[NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
 #pragma unroll
             for (int j = 0; j < NU; ++j) Quu[i][j] = sh[i * 16 + NX + j];
             Qu[i] = sh[64 + NX + i];
             rhs[i][0] = -Qu[i];
-            rhs[i][1] = -sh[i * 16 + c]; // -Qux[i][c]
+            rhs[i][1] = -sh[i * 16 + ci]; // -Qux[i][ci]
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        solve_quu4_fast<double>(Quu, rhs, bad); // k = -Quu^-1 Qu, K[:, c] = -Quu^-1 Qux[:, c]
-        const double kg = g == 0 ? rhs[0][1] : g == 1 ? rhs[1][1] : g == 2 ? rhs[2][1] : rhs[3][1]; // K[g][c]
-        const double kc = cu == 0 ? rhs[0][0] : cu == 1 ? rhs[1][0] : cu == 2 ? rhs[2][0] : rhs[3][0]; // k[cu]
-        if (gain_on) *(double *)(out + ogain) = isx ? kg : kc;
+        solve_quu4_fast<T>(Quu, rhs, bad); // k = -Quu^-1 Qu, K[:, ci] = -Quu^-1 Qux[:, ci]
+        const T kg = g == 0 ? rhs[0][1] : g == 1 ? rhs[1][1] : g == 2 ? rhs[2][1] : rhs[3][1]; // K[g][ci]
+        const T kc = cu == 0 ? rhs[0][0] : cu == 1 ? rhs[1][0] : cu == 2 ? rhs[2][0] : rhs[3][0]; // k[cu]
+        if (gain_on) *(T *)(out + ogain) = isx ? kg : kc;
         // Vx = Qx + K' Qu ; Vxx = Qxx + K' Qux (ilqr.py:104-105)
-        double nvx = qv;
+        T nvx = qv;
 #pragma unroll
         for (int q = 0; q < NU; ++q) nvx = fma_(rhs[q][1], Qu[q], nvx);
-        vx = nvx;
-        TG = __builtin_amdgcn_mfma_f64_16x16x4f64(qg, kg, TG, 0, 0, 0);
+        vx = nvx; // (the lanes of the inputs are never asked for theirs)
+        TG = MF::run(qg, kg, TG);
 #pragma unroll
         for (int r = 0; r < 3; ++r) Vt[r] = TG[r];
     };
     // Iteration i handles step t = T1 - 1 - i from ring slot i mod D and leaves its gains in output
-    // image i mod 2.  Per iteration: wait until this wave's piece of step t has landed, meet (every
-    // piece has landed; every wave is done with the previous step, its gains are in the image),
-    // refill the ring slot and write out the image of the previous step, compute.
+    // image i mod 2.  A direct load is ordered before a read of its data only by the loading wave's
+    // counted wait followed by a barrier, so per iteration: wait until this wave's piece of step t
+    // has landed, meet (every piece has landed; every wave is done with the previous step and its
+    // gains are in the image), refill the ring slot, write out the image of the previous step, compute.
 #pragma unroll
     for (int s = 0; s < D - 1; ++s) stage(T1 - 1 - s > 0 ? T1 - 1 - s : 0, s);
     for (int ib = 0; ib < T1; ib += D) {
@@ -1381,12 +1429,12 @@ static __global__ __launch_bounds__(1024) void ltv12x4_backward_staged_kernel(Pa
         for (int s = 0; s < D; ++s) {
             const int i = ib + s, t = T1 - 1 - i;
             if (t < 0) break; // uniform over the workgroup
-            if (w < 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 2) : "memory");
+            if (w < NLOAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 2) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             stage(t - (D - 1) > 0 ? t - (D - 1) : 0, (s + D - 1) % D);
             if (i > 0) write_out(t + 1, (s + 1) & 1);
-            if (act) one_step(lds + s * LTVB_IN, lds + OFF_OUT + (s & 1) * LTVB_OUT);
+            if (act) one_step(lds + s * IN_BYTES, lds + OFF_OUT + (s & 1) * OUT_BYTES);
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1395,28 +1443,21 @@ static __global__ __launch_bounds__(1024) void ltv12x4_backward_staged_kernel(Pa
     if (act && lane == 0) p.redo[o] = bad ? 1 : 0;
 }
 
-// REDO = false: every selected problem, branch-free solve; a problem whose Quu was not positive
-// definite somewhere is flagged in p.redo.  REDO = true (a second, normally idle launch): only the
-// flagged problems, with the pivoted-LU fallback.  Two kernels, so that the fallback's registers
-// do not cost the main kernel its occupancy.
-template <typename T, bool REDO> __global__ __launch_bounds__(64) void ltv12x4_backward_mfma_kernel(Params<T, 12, 4> p) {
+// The fallback launch behind ltv12x4_backward_staged_kernel (normally idle): the problems it flagged
+// in p.redo, one wave per workgroup each, with the pivoted-LU solve of the lane-per-problem kernel
+// (ilqr.py:99 inverts Quu whatever its signs).  A kernel of its own, so that the fallback's
+// registers do not cost the main kernel its occupancy.
+template <typename T> __global__ __launch_bounds__(64) void ltv12x4_backward_redo_kernel(Params<T, 12, 4> p) {
     __shared__ T sh[80];
     const int lane = threadIdx.x;
-    const int nsl = slot_count(p);
-    // 64 consecutive workgroups of one XCD (workgroups are dealt to the 8 XCDs in turn) take the
-    // 64 problems of one tile, so that their 8-byte pieces of a row meet in that XCD's L2
-    const int bid = blockIdx.x, seq = bid >> 3;
-    const int slot = (((seq >> 6) << 3) + (bid & 7)) * 64 + (seq & 63);
-    if (slot >= nsl) return;
+    const int slot = blockIdx.x;
+    if (slot >= slot_count(p)) return;
     const int o = orig_of(p, slot);
     if (p.select_converged ? (p.converged[o] == 0 || p.carried[o] == 0) : p.converged[o] != 0) return;
-    if (REDO && p.redo[o] == 0) return;
+    if (p.redo[o] == 0) return;
     bool bad = false;
-    const int status = ltv12x4_backward_sweep<!REDO>(p, sh, slot, lane, bad);
-    if (lane == 0) {
-        if (!REDO) p.redo[o] = bad ? 1 : 0;
-        if (status != 0 && p.status) p.status[o] |= status;
-    }
+    const int status = ltv12x4_backward_sweep<false>(p, sh, slot, lane, bad);
+    if (lane == 0 && status != 0 && p.status) p.status[o] |= status;
 }
 
 // ---------------------------------------------------------------- rollout step
@@ -2028,33 +2069,40 @@ __global__ __launch_bounds__(64) void evaluate_listed_kernel(Params<T, M::NX, M:
     if (__ballot(slow) != 0ull) listed_commit<T, M, BARRIER, L, REROLL, false>(p, pipe, Xw, Uw, alpha, slow && al == 0);
 }
 
-// ---------------------------------------------------------------- line search, n = 12, m = 4, fp64
-// One wave per problem on the fp64 matrix unit, all 16 step sizes at once: the candidates are
-// the columns of a 16 x 16 tile Z = [x; u] (rows 0..11 states, 12..15 inputs) in D-layout
-// (layouts: see ltv12x4_backward_mfma_kernel), so lane (c, g) carries candidate c and the
-// components g, g+4, g+8 of its state and input g.  A time step is X+ = [A_t | B_t] Z (four
-// calls) after the feedback K (X - x_prev) (three calls, result row g = input g in the lane that
-// holds that input).  Each lane accumulates its share of the candidate's cost; the four lanes of
-// a candidate are summed at the end.  Sums run in the matrix unit's order: costs and the accepted
-// step agree with the lane-per-candidate kernel to rounding, not bit for bit.
+// ---------------------------------------------------------------- line search, n = 12, m = 4
+// One wave per problem on the matrix unit, all 16 step sizes at once: the candidates are the
+// columns of a 16 x 16 tile Z = [x; u] (rows 0..11 states, 12..15 inputs; layouts: see Mfma4 and
+// ltv12x4_backward_sweep), so lane (c, g) carries candidate c and the components g, g+4, g+8 of
+// its state and input g.  A time step is X+ = [A_t | B_t] Z (four calls) after the feedback
+// K (X - x_prev) (three calls, result row g = input g in the lane that holds that input).  Each
+// lane accumulates its share of the candidate's cost; the four lanes of a candidate are summed at
+// the end.  Sums run in the matrix unit's order: costs and the accepted step agree with the
+// lane-per-candidate kernel to rounding, not bit for bit.
 //
 // A workgroup is 16 waves = 16 neighbouring problems of a tile.  A problem's share of a row is 8
-// bytes of a 128-byte line that the 16 problems share, and a wave that loads its own operands
-// touches 16 to 64 lines per load instruction, which the texture-address unit works through one
-// line at a time (measured: the kernel ran at the speed of that unit, not of the matrix unit or of
-// HBM).  So the workgroup fetches the 80 rows of a time step (K, k, x, u, xref: one 128-byte line
-// each for its 16 problems) and that step's [A_t | B_t] (shared by all problems) as whole lines
-// straight into LDS (12 wave instructions of 1 KiB per step instead of 240 scattered ones), LTV_RING
-// steps ahead, and every wave takes its operands from there.
+// (4) bytes of a line that the 16 problems share, and a wave that loads its own operands touches
+// 16 to 64 lines per load instruction, which the texture-address unit works through one line at a
+// time (measured: the kernel ran at the speed of that unit, not of the matrix unit or of HBM).  So
+// the workgroup fetches the 80 rows of a time step (K, k, x, u, xref: one line each for its 16
+// problems) and that step's [A_t | B_t] (shared by all problems) as whole lines straight into LDS
+// (12 wave instructions of 1 KiB per step in fp64 instead of 240 scattered ones), LTV_RING steps
+// ahead, and every wave takes its operands from there.
 //
 // LDS image of one step: 16-byte granules in the order the loading lanes hold them (the direct
-// load writes lane i of a wave at base + 16 i).  Granule 8 r + j of row r holds the problems
-// 2 P, 2 P + 1 with P = (j - r / 2) mod 8: a wave reads the same problem of 16 different rows in
-// one instruction, and the rotation puts those 16 on 16 different bank groups.
-static __global__ __launch_bounds__(1024) void ltv12x4_evaluate_mfma_kernel(Params<double, 12, 4> p) {
-    constexpr int NX = 12, NU = 4, D = LTV_RING;
-    __shared__ __attribute__((aligned(16))) unsigned char ring[D * LTV_CHUNK];
+// load writes lane i of a wave at base + 16 i), rotated within each row (LtvStage): a wave reads
+// the same problem of 16 different rows in one instruction, and the rotation puts those 16 on 16
+// different bank groups.
+template <typename T> __global__ __launch_bounds__(1024) void ltv12x4_evaluate_mfma_kernel(Params<T, 12, 4> p) {
+    using St = LtvStage<T>;
+    using MF = Mfma4<T>;
+    using acc = typename MF::acc;
+    constexpr int NX = 12, NU = 4, D = LTV_RING, ES = (int)sizeof(T), GPR = St::GPR, PPG = St::PPG;
+    constexpr int ROWS = 80; // rows of a step: K 0..47, k 48..51, x 52..63, u 64..67, xref 68..79
+    constexpr int AGR = NX * NX * ES / 16, TBL = NX * (NX + NU) * ES / 16;
+    constexpr int NLOAD = (ROWS * GPR + TBL + 63) / 64, CHUNK = NLOAD * 1024;
+    __shared__ __attribute__((aligned(16))) unsigned char ring[D * CHUNK];
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int ci = MF::tau(c);                                      // the row of a left factor this lane supplies
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave = problem of the workgroup
     const int nsl = slot_count(p);
     const int slot0 = blockIdx.x * 16, slot_raw = slot0 + w;
@@ -2064,83 +2112,83 @@ static __global__ __launch_bounds__(1024) void ltv12x4_evaluate_mfma_kernel(Para
     if (!__syncthreads_or(act)) return; // no wave of this workgroup has work
     const int T1 = p.N - 1;
     const int tile = slot0 >> 6, ln0 = slot0 & 63; // the workgroup's 16 problems: lanes ln0 .. ln0 + 15 of one tile
-    const double *Xt = tile_ptr(p.X, tile, p.N * NX, ln0);
-    const double *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln0);
-    const double alpha = pow2_neg<double>(c);
-    double qw[3], qfw[3];
+    const T *Xt = tile_ptr(p.X, tile, p.N * NX, ln0);
+    const T *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln0);
+    const T alpha = pow2_neg<T>(c);
+    T qw[3], qfw[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         qw[r] = p.Q[(g + 4 * r) * NX + g + 4 * r];
         qfw[r] = p.Qf[(g + 4 * r) * NX + g + 4 * r];
     }
-    const double rw = p.R[g * NU + g], lo = p.lo[g], hi = p.hi[g];
+    const T rw = p.R[g * NU + g], lo = p.lo[g], hi = p.hi[g];
     // candidates start from the stored first state
-    double z[4], cost = 0.0;
+    T z[4], cost = T(0);
 #pragma unroll
     for (int r = 0; r < 3; ++r) z[r] = Xt[(size_t)(g + 4 * r) * TILE + w];
-    z[3] = 0.0;
+    z[3] = T(0);
     // this lane's granule of every step: source address at step 0 and its stride per step
     const unsigned char *src;
     unsigned stride;
     {
-        const int q = threadIdx.x, row = q >> 3, part = ((q & 7) - (row >> 1)) & 7;
-        if (q < 8 * LTV_ROWS) {
-            const double *b;
+        const int q = threadIdx.x, row = q / GPR;
+        if (q < ROWS * GPR) {
+            const T *b;
             int r, rows;
             if (row < 48) b = tile_ptr(p.K, tile, T1 * NU * NX, ln0), r = row, rows = NU * NX;
             else if (row < 52) b = tile_ptr(p.k, tile, T1 * NU, ln0), r = row - 48, rows = NU;
             else if (row < 64) b = Xt, r = row - 52, rows = NX;
             else if (row < 68) b = tile_ptr(p.U, tile, T1 * NU, ln0), r = row - 64, rows = NU;
             else b = Rt, r = row - 68, rows = NX;
-            src = (const unsigned char *)(b + (size_t)r * TILE + 2 * part);
-            stride = (unsigned)(rows * TILE * sizeof(double));
+            src = (const unsigned char *)(b + (size_t)r * TILE + St::first_problem(q));
+            stride = (unsigned)(rows * TILE * ES);
         } else {
-            const int e = q - 8 * LTV_ROWS < 96 ? q - 8 * LTV_ROWS : 95; // 72 granules of A_t, 24 of B_t (the padding repeats the last)
-            src = (const unsigned char *)(e < 72 ? p.ltvA + 2 * e : p.ltvB + 2 * (e - 72));
-            stride = (unsigned)((e < 72 ? NX * NX : NX * NU) * sizeof(double));
+            const int e = q - ROWS * GPR < TBL ? q - ROWS * GPR : TBL - 1; // (padding lanes repeat the last granule)
+            src = (const unsigned char *)(e < AGR ? p.ltvA + PPG * e : p.ltvB + PPG * (e - AGR));
+            stride = (unsigned)((e < AGR ? NX * NX : NX * NU) * ES);
         }
     }
     auto stage = [&](int t, int buf) {
-        if (w < 12) glds16(src + (size_t)t * stride, ring + buf * LTV_CHUNK + w * 1024);
+        if (w < NLOAD) glds16(src + (size_t)t * stride, ring + buf * CHUNK + w * 1024);
     };
-    // where this lane's operands sit in a step's image.  The matrix instruction's left operand of
-    // lane (c, g) is row c of the left factor: rows >= 4 of K and rows >= 12 of [A_t | B_t] only
-    // produce result rows nobody reads, so those lanes simply read a valid row.
+    // where this lane's operands sit in a step's image.  The matrix instruction's left operand of a
+    // lane is one row of the left factor: rows >= 4 of K and rows >= 12 of [A_t | B_t] only produce
+    // result rows nobody reads, so those lanes simply read a valid row.
     unsigned oxp[3], oxr[3], oK[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-        oxp[q] = ltv_lds_off(52 + g + 4 * q, w);
-        oxr[q] = ltv_lds_off(68 + g + 4 * q, w);
-        oK[q] = ltv_lds_off((c & 3) * NX + g + 4 * q, w);
+        oxp[q] = St::off(52 + g + 4 * q, w);
+        oxr[q] = St::off(68 + g + 4 * q, w);
+        oK[q] = St::off((ci & 3) * NX + g + 4 * q, w);
     }
-    const unsigned oup = ltv_lds_off(64 + g, w), okf = ltv_lds_off(48 + g, w);
-    const int cc = c < NX ? c : 0;
-    const unsigned oA = 8 * LTV_ROWS * 16 + (cc * NX + g) * 8, oB = 8 * LTV_ROWS * 16 + NX * NX * 8 + (cc * NU + g) * 8;
+    const unsigned oup = St::off(64 + g, w), okf = St::off(48 + g, w);
+    const int cc = ci < NX ? ci : 0;
+    const unsigned oA = ROWS * GPR * 16 + (cc * NX + g) * ES, oB = ROWS * GPR * 16 + NX * NX * ES + (cc * NU + g) * ES;
     auto one_step = [&](const unsigned char *img) {
-        auto at = [&](unsigned off) { return *(const double *)(img + off); };
-        double dx[3], e[3];
+        auto at = [&](unsigned off) { return *(const T *)(img + off); };
+        T dx[3], e[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             dx[q] = z[q] - at(oxp[q]);
             e[q] = z[q] - at(oxr[q]);
         }
-        v4f64_ KD = {0.0, 0.0, 0.0, 0.0};
+        acc KD = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-        for (int q = 0; q < 3; ++q) KD = __builtin_amdgcn_mfma_f64_16x16x4f64(at(oK[q]), dx[q], KD, 0, 0, 0);
+        for (int q = 0; q < 3; ++q) KD = MF::run(at(oK[q]), dx[q], KD);
         // u_new = (u_prev + alpha k) + K (x_new - x_prev), clamped (ilqr.py:56-61)
-        double v = fma_(alpha, at(okf), at(oup)) + KD[0];
+        T v = fma_(alpha, at(okf), at(oup)) + KD[0];
         v = (lo > v) ? lo : v;
         v = (hi < v) ? hi : v;
         z[3] = v;
-        double stage_cost = (qw[0] * e[0]) * e[0];
+        T stage_cost = (qw[0] * e[0]) * e[0];
         stage_cost = fma_(qw[1] * e[1], e[1], stage_cost);
         stage_cost = fma_(qw[2] * e[2], e[2], stage_cost);
         stage_cost = fma_(rw * v, v, stage_cost);
         cost += stage_cost;
-        v4f64_ Xn = {0.0, 0.0, 0.0, 0.0};
+        acc Xn = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-        for (int q = 0; q < 3; ++q) Xn = __builtin_amdgcn_mfma_f64_16x16x4f64(at(oA + 32 * q), z[q], Xn, 0, 0, 0);
-        Xn = __builtin_amdgcn_mfma_f64_16x16x4f64(at(oB), z[3], Xn, 0, 0, 0);
+        for (int q = 0; q < 3; ++q) Xn = MF::run(at(oA + 4 * ES * q), z[q], Xn);
+        Xn = MF::run(at(oB), z[3], Xn);
 #pragma unroll
         for (int q = 0; q < 3; ++q) z[q] = Xn[q];
     };
@@ -2159,133 +2207,29 @@ static __global__ __launch_bounds__(1024) void ltv12x4_evaluate_mfma_kernel(Para
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 2) : "memory");
             __builtin_amdgcn_s_barrier();
             stage(t + D - 1 < T1 ? t + D - 1 : T1 - 1, (s + D - 1) % D);
-            if (act) one_step(ring + s * LTV_CHUNK);
+            if (act) one_step(ring + s * CHUNK);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     {   // terminal term (ilqr.py:44-45)
-        double term = 0.0;
+        T term = T(0);
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            const double e = z[q] - Rt[(size_t)(T1 * NX + g + 4 * q) * TILE + w];
+            const T e = z[q] - Rt[(size_t)(T1 * NX + g + 4 * q) * TILE + w];
             term = fma_(qfw[q] * e, e, term);
         }
         cost += term;
     }
-    const double Jcur = p.J[o];
+    const T Jcur = p.J[o];
     cost += __shfl_xor(cost, 16);
     cost += __shfl_xor(cost, 32);
     // lowest step index whose cost improves strictly (ilqr.py:65; NaN never passes)
     const unsigned long long win = __ballot(g == 0 && c < p.n_alphas && cost < Jcur);
     const int best = win ? __ffsll((long long)win) - 1 : -1;
-    const double best_cost = __shfl(cost, best < 0 ? 0 : best);
+    const T best_cost = __shfl(cost, best < 0 ? 0 : best);
     if (act && lane == 0) {
         p.alpha_idx[o] = best;
-        p.Jtry[o] = best < 0 ? 0.0 : best_cost;
-        p.slow_trig[o] = p.slow_trig[o] & 6;
-    }
-}
-
-// fp32 variant (v_mfma_f32_16x16x4, register r of lane (c, g) = M[4 g + r][c]): lane groups 0..2
-// carry the states 4 g + r of candidate c, lane group 3 its four inputs; the feedback K dX comes
-// out in lane group 0 and is passed to lane group 3.
-static __global__ __launch_bounds__(1024) void ltv12x4_evaluate_mfma_f32_kernel(Params<float, 12, 4> p) {
-    constexpr int NX = 12, NU = 4;
-    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    const bool g3 = g == 3;
-    const int nsl = slot_count(p);
-    const int slot_raw = blockIdx.x * 16 + (threadIdx.x >> 6);
-    const int slot = slot_raw < nsl ? slot_raw : (nsl > 0 ? nsl - 1 : 0);
-    const int o = orig_of(p, slot);
-    const bool act = slot_raw < nsl && p.converged[o] == 0;
-    if (!__syncthreads_or(act)) return;
-    const int T1 = p.N - 1;
-    const int tile = slot >> 6, ln = slot & 63;
-    const float *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
-    const float *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
-    const float *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
-    const float *kp = tile_ptr(p.k, tile, T1 * NU, ln);
-    const float *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
-    const float Jcur = p.J[o];
-    const float alpha = pow2_neg<float>(c);
-    float w[4], wf[4], lo[4], hi[4]; // stage / terminal weight of this lane's four components, input box
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int j = g3 ? 0 : 4 * g + r;
-        w[r] = g3 ? p.R[r * NU + r] : p.Q[j * NX + j];
-        wf[r] = g3 ? 0.0f : p.Qf[j * NX + j];
-        lo[r] = p.lo[r];
-        hi[r] = p.hi[r];
-    }
-    struct Row {
-        float a[4], b[4], Kop[4], Fop[4]; // a: x_prev (groups 0..2) / u_prev (group 3); b: xref / k
-    };
-    auto load_row = [&](int t, Row &r) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = g3 ? 0 : 4 * g + q;
-            r.a[q] = g3 ? Ut[(size_t)(t * NU + q) * TILE] : Xt[(size_t)(t * NX + j) * TILE];
-            r.b[q] = g3 ? kp[(size_t)(t * NU + q) * TILE] : Rt[(size_t)(t * NX + j) * TILE];
-            const float kv = Kp[(size_t)((t * NU + (c & 3)) * NX + j) * TILE];                    // K[c][4g + q]
-            r.Kop[q] = (c < NU && !g3) ? kv : 0.0f;
-            const int cc = c < NX ? c : 0;
-            const float fv = g3 ? p.ltvB[(size_t)t * NX * NU + cc * NU + q] : p.ltvA[(size_t)t * NX * NX + cc * NX + j];
-            r.Fop[q] = c < NX ? fv : 0.0f;                                                         // F[c][4g + q]
-        }
-    };
-    float z[4], cost = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) z[r] = g3 ? 0.0f : Xt[(size_t)(4 * g + r) * TILE];
-    Row nxt;
-    load_row(0, nxt);
-    for (int t = 0; t < T1; ++t) {
-        if ((t & (LTV_SYNC_EVERY - 1)) == 0) __syncthreads();
-        if (!act) continue; // wave-uniform
-        const Row r = nxt;
-        load_row(t + 1 < T1 ? t + 1 : t, nxt);
-        float dx[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dx[q] = g3 ? 0.0f : z[q] - r.a[q];
-        v4f32_ KD = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) KD = __builtin_amdgcn_mfma_f32_16x16x4f32(r.Kop[q], dx[q], KD, 0, 0, 0);
-        float val[4]; // what the stage cost squares: x - xref (groups 0..2), the new input (group 3)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float fb = __shfl(KD[q], c); // (K dX)[q][c] from lane group 0
-            float v = fma_(alpha, r.b[q], r.a[q]) + fb;
-            v = (lo[q] > v) ? lo[q] : v;
-            v = (hi[q] < v) ? hi[q] : v;
-            val[q] = g3 ? v : z[q] - r.b[q];
-            z[q] = g3 ? v : z[q];
-        }
-        float stage = (w[0] * val[0]) * val[0];
-#pragma unroll
-        for (int q = 1; q < 4; ++q) stage = fma_(w[q] * val[q], val[q], stage);
-        cost += stage;
-        v4f32_ Xn = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Xn = __builtin_amdgcn_mfma_f32_16x16x4f32(r.Fop[q], z[q], Xn, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) z[q] = g3 ? 0.0f : Xn[q];
-    }
-    {
-        float term = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float e = g3 ? 0.0f : z[q] - Rt[(size_t)(T1 * NX + (g3 ? 0 : 4 * g + q)) * TILE];
-            term = fma_(wf[q] * e, e, term);
-        }
-        cost += term;
-    }
-    cost += __shfl_xor(cost, 16);
-    cost += __shfl_xor(cost, 32);
-    const unsigned long long win = __ballot(g == 0 && c < p.n_alphas && cost < Jcur);
-    const int best = win ? __ffsll((long long)win) - 1 : -1;
-    const float best_cost = __shfl(cost, best < 0 ? 0 : best);
-    if (act && lane == 0) {
-        p.alpha_idx[o] = best;
-        p.Jtry[o] = best < 0 ? 0.0f : best_cost;
+        p.Jtry[o] = best < 0 ? T(0) : best_cost;
         p.slow_trig[o] = p.slow_trig[o] & 6;
     }
 }

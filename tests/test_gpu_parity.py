@@ -610,6 +610,34 @@ def test_ltv12x4_indefinite_quu_uses_the_fallback_launch(ilqr_cls, oracle):
         assert nrm(opt.K[b], Ko) <= 1e-9 and nrm(opt.k[b][:, :, 0], ko) <= 1e-9
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_ltv12x4_unselected_neighbours_keep_their_gains(ilqr_cls, dtype):
+    """The matrix-unit backward kernel handles 16 neighbouring problems per workgroup and writes
+    their gains as shared lines: problems of the 16 that are converged (not selected) must keep
+    the stored gains bit for bit, the others must get the bits they get when all are selected."""
+    import torch
+    from ilqr_amd import problems
+    N, B = 50, 41
+    s = ltv_setup(N)
+    p = problems.ltv_batch(B, N)
+    opt = ilqr_cls(s, p["target_states"], s.dt, dtype=dtype)
+    opt.inputs, opt.states = p["init_inputs"].copy(), p["init_states"].copy()
+    dev = opt.upload()
+    dev.initial_cost()
+    dev.backward()
+    K_all, k_all = dev.download_K().copy(), dev.download_k().copy()
+    skip = np.zeros(B, dtype=bool)
+    skip[[1, 2, 3, 17, 30, 31, 40]] = True
+    skip[16:20] = True                                    # a whole granule of the fp32 layout, half a workgroup's line
+    dev.converged.copy_(torch.from_numpy(skip.astype(np.int32)))
+    dev.K.fill_(7.0)
+    dev.k.fill_(7.0)
+    dev.backward()
+    K, k = dev.download_K(), dev.download_k()
+    assert np.array_equal(K[~skip], K_all[~skip]) and np.array_equal(k[~skip], k_all[~skip])
+    assert np.all(K[skip] == 7.0) and np.all(k[skip] == 7.0)
+
+
 def test_ltv12x4_fp32_mode(ilqr_cls, oracle):
     from ilqr_amd import problems
     N, B = 120, 8
