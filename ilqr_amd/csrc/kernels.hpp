@@ -1369,26 +1369,27 @@ template <typename T> __global__ __launch_bounds__(1024) void ltv12x4_backward_s
         part += __shfl_xor(part, 16);
         part += __shfl_xor(part, 32);
         const T qv = fma_(lw, xu_c - xr_c, part);
-        // W = (Vxx + lm I) F, G = F' W in both layouts (see ltv12x4_backward_sweep).  Lanes that stand
-        // for an input hold rows 12..15 of the left factor, which only produce rows of the result that
-        // no later product reads: they need no masking anywhere below.
+        // W = (Vxx + lm I) F, then G = F' W with register r of lane (ci, g) = G[ci][g + 4 r] (layouts:
+        // see ltv12x4_backward_sweep).  Lanes that stand for an input hold rows 12..15 of the left
+        // factor of W, which only produce rows that no later product reads: no masking needed.
         acc W = {T(0), T(0), T(0), T(0)};
         W = MF::run(Vt[0] + lmd[0], F0, W);
         W = MF::run(Vt[1] + lmd[1], F1, W);
         W = MF::run(Vt[2] + lmd[2], F2, W);
-        acc TG = {T(0), T(0), T(0), T(0)}, DG = {T(0), T(0), T(0), T(0)};
+        acc TG = {T(0), T(0), T(0), T(0)};
         TG = MF::run(W[0], F0, TG);
         TG = MF::run(W[1], F1, TG);
         TG = MF::run(W[2], F2, TG);
-        DG = MF::run(F0, W[0], DG);
-        DG = MF::run(F1, W[1], DG);
-        DG = MF::run(F2, W[2], DG);
         // + lxx = 2Q, luu = 2R on the diagonal (ilqr.py:91-92)
 #pragma unroll
         for (int r = 0; r < 4; ++r) TG[r] += lwd[r];
-        const T qg = DG[3] + lwd[3]; // Qux[g][ci] (ci < 12), Quu[g][ci - 12] (ci >= 12)
-        // exchange through the wave's own LDS words: a wave's LDS accesses execute in order
-        sh[g * 16 + ci] = qg;
+        // The lanes of the inputs hold the rows [Qux | Quu] of G in their registers (register r of
+        // lane (ci, g) is G[ci][g + 4 r]): they pass them to everybody through the wave's own LDS
+        // words (a wave's LDS accesses execute in order), which saves the product in the other layout.
+        if (!isx) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sh[cu * 16 + g + 4 * r] = TG[r];
+        }
         if (g == 0) sh[64 + ci] = qv;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1402,6 +1403,7 @@ template <typename T> __global__ __launch_bounds__(1024) void ltv12x4_backward_s
             rhs[i][0] = -Qu[i];
             rhs[i][1] = -sh[i * 16 + ci]; // -Qux[i][ci]
         }
+        const T qg = sh[g * 16 + ci]; // Qux[g][ci] (ci < 12), Quu[g][ci - 12] (ci >= 12)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         solve_quu4_fast<T>(Quu, rhs, bad); // k = -Quu^-1 Qu, K[:, ci] = -Quu^-1 Qux[:, ci]
