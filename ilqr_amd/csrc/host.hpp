@@ -443,6 +443,15 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
     }
     template <bool REROLL> static hipError_t commit_r(const HostCtx &c, int it, hipStream_t s) {
         auto p = make_params<T, NX, NU>(c);
+        if constexpr (std::is_same<M, LtvModelT<T, 12, 4>>::value && DIAG) {
+            // 16 problems per wave on the matrix unit (kernels.hpp), whenever the line search was the
+            // single-stage matrix-unit kernel
+            static const bool generic = getenv("ILQR_LTV_GENERIC") != nullptr;
+            if (!barrier_on(c) && c.n_alphas <= 16 && !generic) {
+                hipLaunchKernelGGL(ltv12x4_commit_mfma_kernel<T>, dim3((c.count + 63) / 64), dim3(256), 0, s, p, it, REROLL ? 0 : 1);
+                return hipGetLastError();
+            }
+        }
         if constexpr (M::NX <= 8) {
             if (use_seg(c)) {
                 const int nseg = commit_segments(c.d);

@@ -2412,6 +2412,133 @@ __global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, i
         commit_sweep<T, M, 1, REROLL, false, TC>(p, Xt, Ut, Kp, kp, trash, alpha, slow, keep_ok, pend, !slow, SCt);
 }
 
+// ---------------------------------------------------------------- commit, n = 12, m = 4
+// The accepted step size rolled out with 16 problems per wave: the problems are the columns of the
+// tile Z = [x; u] (lane (c, g): problem c of the wave, state components g, g+4, g+8 and input g),
+// so X+ = [A_t | B_t] Z is four matrix instructions for 16 problems (the tables are the same for
+// all problems), and the 16 lanes of a lane group read and write 16 neighbouring problems of a row:
+// whole lines.  The feedback K (x - x_prev) has a gain matrix per problem and stays on the vector
+// unit: every lane multiplies its three components, the four lanes of a problem add up.
+// A workgroup is the four waves of one tile.  (One lane per problem leaves 512 waves for 32768
+// problems, half a wave per SIMD, each with a 12 x 12 product per step.)
+// Lanes whose problem keeps its trajectory write back what they read: every store is a full line.
+// `first`: the caller wrote the trajectories since the last commit (see commit_kernel, slow_trig).
+template <typename T> __global__ __launch_bounds__(256) void ltv12x4_commit_mfma_kernel(Params<T, 12, 4> p, int it, int first) {
+    using MF = Mfma4<T>;
+    using acc = typename MF::acc;
+    constexpr int NX = 12, NU = 4, PF = 2;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int w = threadIdx.x >> 6;
+    const int nsl = slot_count(p);
+    if (nsl <= 0) return;
+    const int tile = blockIdx.x, ln = 16 * w + c;
+    const int b0 = tile * 64 + ln;
+    const bool valid = b0 < nsl;
+    const int b = orig_of(p, valid ? b0 : nsl - 1);
+    const bool active = valid && p.converged[b] == 0;
+    if (__ballot(active) == 0ull) return;
+    const int T1 = p.N - 1;
+    const int idx = p.alpha_idx[b];
+    const bool pend = active && idx == -2;
+    const bool roll = active && idx >= 0;
+    if (g == 0) { // per-problem outcome, as in commit_kernel
+        const int slow_bits = p.slow_trig[b];
+        if (valid && !pend) {
+            const int committed = roll ? 4 : 0;
+            if (first)
+                p.slow_trig[b] = (slow_bits & 1) | committed;
+            else if (roll)
+                p.slow_trig[b] = slow_bits | committed;
+        }
+        if (active && !pend) {
+            p.iters[b] += 1;
+            const T Jn = roll ? p.Jtry[b] : p.J[b];
+            if (roll) {
+                p.J[b] = Jn;
+                if (p.status && !(fabs_(Jn) < inf_<T>())) p.status[b] |= ILQR_STATUS_NONFINITE_;
+            } else {
+                p.converged[b] = 1;
+            }
+            if (it < p.hist_cap) {
+                if (p.hist_cost) p.hist_cost[size_t(it) * p.hist_stride + b] = Jn;
+                if (p.hist_alpha) p.hist_alpha[size_t(it) * p.hist_stride + b] = idx;
+            }
+        }
+    }
+    if (__ballot(roll) == 0ull) return;
+    T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
+    T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
+    const T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
+    const T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    const T alpha = pow2_neg<T>(roll ? idx : 0);
+    const T lo = p.lo[g], hi = p.hi[g];
+    // left operand of X+ = [A_t | B_t] Z: this lane supplies row ci of the tables (rows >= 12 only
+    // produce result rows nobody reads: a valid row is read instead)
+    const int ci = MF::tau(c), cc = ci < NX ? ci : 0;
+    const T *Ap = p.ltvA + cc * NX + g, *Bp = p.ltvB + cc * NU + g;
+    struct Row {
+        T xp[3], K[NU][3], up, kf, F[4];
+    };
+    auto load_row = [&](int t, Row &r) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            r.xp[q] = Xt[(size_t)(t * NX + g + 4 * q) * TILE];
+            r.F[q] = Ap[(size_t)t * (NX * NX) + 4 * q];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) r.K[i][q] = Kp[(size_t)((t * NU + i) * NX + g + 4 * q) * TILE];
+        }
+        r.F[3] = Bp[(size_t)t * (NX * NU)];
+        r.up = Ut[(size_t)(t * NU + g) * TILE];
+        r.kf = kp[(size_t)(t * NU + g) * TILE];
+    };
+    T x[3], xlast[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        x[q] = Xt[(size_t)(g + 4 * q) * TILE];
+        xlast[q] = Xt[(size_t)(T1 * NX + g + 4 * q) * TILE];
+    }
+    // every row is read before any store reaches it: the ring holds rows t .. t+PF-1 while step t
+    // writes the inputs of row t and the states of row t+1
+    Row ring[PF];
+#pragma unroll
+    for (int s = 0; s < PF; ++s) load_row(s < T1 ? s : T1 - 1, ring[s]);
+    for (int tb = 0; tb < T1; tb += PF) {
+#pragma unroll
+        for (int sl = 0; sl < PF; ++sl) {
+            const int t = tb + sl;
+            if (t >= T1) break;
+            const Row r = ring[sl];
+            load_row(t + PF < T1 ? t + PF : T1 - 1, ring[sl]);
+            const Row &nxt = ring[(sl + 1) % PF]; // row t+1 (if there is one)
+            // u_new = (u_prev + alpha k) + K (x_new - x_prev), clamped (ilqr.py:56-61)
+            T dx[3], fb[NU];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) dx[q] = x[q] - r.xp[q];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                fb[i] = r.K[i][0] * dx[0];
+                fb[i] = fma_(r.K[i][1], dx[1], fb[i]);
+                fb[i] = fma_(r.K[i][2], dx[2], fb[i]);
+                fb[i] += __shfl_xor(fb[i], 16);
+                fb[i] += __shfl_xor(fb[i], 32);
+            }
+            T v = fma_(alpha, r.kf, r.up) + (g == 0 ? fb[0] : g == 1 ? fb[1] : g == 2 ? fb[2] : fb[3]);
+            v = (lo > v) ? lo : v;
+            v = (hi < v) ? hi : v;
+            acc Xn = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) Xn = MF::run(r.F[q], x[q], Xn);
+            Xn = MF::run(r.F[3], v, Xn);
+            Ut[(size_t)(t * NU + g) * TILE] = roll ? v : r.up;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                x[q] = Xn[q];
+                Xt[(size_t)((t + 1) * NX + g + 4 * q) * TILE] = roll ? Xn[q] : (t + 1 < T1 ? nxt.xp[q] : xlast[q]);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- commit, all segments at once
 // The rollout of the accepted step size is a recurrence over the horizon, and with one lane per
 // problem a small batch leaves most of the chip idle for its whole length.  With the candidates'
