@@ -1218,6 +1218,15 @@ __device__ __forceinline__ int ltv12x4_backward_sweep(const Params<float, 12, 4>
 // ---------------------------------------------------------------- LDS staging of the n = 12 kernels
 // (the layout is described at ltv12x4_evaluate_mfma_kernel)
 constexpr int LTV_RING = 4;
+// time steps between two meetings of a workgroup's waves (the ring moves in groups of this many
+// steps): with a meeting every step the waves of a SIMD all want the matrix unit, then all the
+// vector unit; with a few steps between meetings they drift apart and the units overlap
+#ifndef LTV_BACKWARD_GROUP
+#define LTV_BACKWARD_GROUP 2
+#endif
+#ifndef LTV_EVALUATE_GROUP
+#define LTV_EVALUATE_GROUP 2
+#endif
 __device__ __forceinline__ void glds16(const void *src, void *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
@@ -1266,12 +1275,12 @@ template <typename T> __global__ __launch_bounds__(1024) void ltv12x4_backward_s
     using St = LtvStage<T>;
     using MF = Mfma4<T>;
     using acc = typename MF::acc;
-    constexpr int NX = 12, NU = 4, D = LTV_RING, ES = (int)sizeof(T), GPR = St::GPR, PPG = St::PPG;
+    constexpr int NX = 12, NU = 4, D = LTV_RING, S = LTV_BACKWARD_GROUP, ES = (int)sizeof(T), GPR = St::GPR, PPG = St::PPG;
     constexpr int IN_ROWS = 28, OUT_ROWS = 52, AGR = NX * NX * ES / 16, TBL = NX * (NX + NU) * ES / 16;
     constexpr int NLOAD = (IN_ROWS * GPR + TBL + 63) / 64, NSTORE = (OUT_ROWS * GPR + 63) / 64; // waves that load / that store
     constexpr int IN_BYTES = NLOAD * 1024, OUT_BYTES = NSTORE * 1024;
-    constexpr int OFF_OUT = D * IN_BYTES, OFF_SH = OFF_OUT + 2 * OUT_BYTES, OFF_FLAG = OFF_SH + 16 * 80 * ES;
-    static_assert(NLOAD + NSTORE <= 16, "wave roles");
+    constexpr int OFF_OUT = D * S * IN_BYTES, OFF_SH = OFF_OUT + 2 * S * OUT_BYTES, OFF_FLAG = OFF_SH + 16 * 16 * ES;
+    static_assert(NLOAD + NSTORE <= 16 && D % 2 == 0, "wave roles, image parity");
     __shared__ __attribute__((aligned(16))) unsigned char lds[OFF_FLAG + 64];
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const int ci = MF::tau(c); // the row / column of the 16 x 16 tiles this lane stands for
@@ -1356,9 +1365,18 @@ template <typename T> __global__ __launch_bounds__(1024) void ltv12x4_backward_s
     // where this lane's operands sit in a step's input image, and its gain in the output image
     const unsigned oxu = St::off(ci, w), oxr = St::off(16 + (isx ? ci : 0), w);
     const unsigned oF = IN_ROWS * GPR * 16 + (isx ? (g * NX + ci) * ES : NX * NX * ES + (g * NU + cu) * ES), oFk = isx ? 4 * NX * ES : 4 * NU * ES;
-    const unsigned ogain = St::off(isx ? g * NX + ci : 48 + cu, w);
-    const bool gain_on = isx || g == 0;
-    T *sh = (T *)(lds + OFF_SH) + w * 80;
+    const unsigned ogain = St::off(isx ? g * NX + ci : 48 + g, w);
+    const bool gain_on = isx || ci == NX;
+    T *sh = (T *)(lds + OFF_SH) + w * 16; // Quu of this wave's problem, row-major
+    // lane (i, j) = (ci, g), i < 4, computes entry (i, j) of the inverse = cofactor (j, i) / det: the
+    // entry (j, i) of Quu and the nine entries of the rows j+1.. and the columns i+1.. (cyclically)
+    int oq[10];
+    oq[0] = g * 4 + (ci & 3);
+#pragma unroll
+    for (int r = 1; r < 4; ++r)
+#pragma unroll
+        for (int q = 1; q < 4; ++q) oq[(r - 1) * 3 + q] = ((g + r) & 3) * 4 + (((ci & 3) + q) & 3);
+    const T csign = ((ci + g) & 1) ? T(-1) : T(1);
     bool bad = false;
     auto one_step = [&](const unsigned char *img, unsigned char *out) {
         const T xu_c = *(const T *)(img + oxu), xr_raw = *(const T *)(img + oxr);
@@ -1383,65 +1401,99 @@ template <typename T> __global__ __launch_bounds__(1024) void ltv12x4_backward_s
         // + lxx = 2Q, luu = 2R on the diagonal (ilqr.py:91-92)
 #pragma unroll
         for (int r = 0; r < 4; ++r) TG[r] += lwd[r];
-        // The lanes of the inputs hold the rows [Qux | Quu] of G in their registers (register r of
-        // lane (ci, g) is G[ci][g + 4 r]): they pass them to everybody through the wave's own LDS
-        // words (a wave's LDS accesses execute in order), which saves the product in the other layout.
-        if (!isx) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sh[cu * 16 + g + 4 * r] = TG[r];
-        }
-        if (g == 0) sh[64 + ci] = qv;
+        // Quu^-1 by cofactors, one entry per lane.  Input lane (12 + i, j) holds Quu[i][j] (register 3)
+        // and leaves it in the wave's own LDS words (a wave's LDS accesses execute in order); lane
+        // (i, j), i < 4, reads the matrix with rows and columns rotated so that entry (j, i) comes
+        // first, takes the 3 x 3 determinant of the rest (the minor: a rotation of three rows is even)
+        // and the four lanes j of an i add up a_ji C_ji to the determinant (expansion along column i).
+        if (!isx) sh[cu * 4 + g] = TG[3];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        T Quu[NU][NU], rhs[NU][2], Qu[NU];
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {
-#pragma unroll
-            for (int j = 0; j < NU; ++j) Quu[i][j] = sh[i * 16 + NX + j];
-            Qu[i] = sh[64 + NX + i];
-            rhs[i][0] = -Qu[i];
-            rhs[i][1] = -sh[i * 16 + ci]; // -Qux[i][ci]
+        T cof = T(0), a_ij = T(0);
+        bool pd = true;
+        if (ci < NU) {
+            const T b11 = sh[oq[1]], b12 = sh[oq[2]], b13 = sh[oq[3]], b21 = sh[oq[4]], b22 = sh[oq[5]], b23 = sh[oq[6]], b31 = sh[oq[7]],
+                    b32 = sh[oq[8]], b33 = sh[oq[9]];
+            a_ij = sh[oq[0]];
+            const T m1 = fma_(b22, b33, -(b23 * b32)), m2 = fma_(b21, b33, -(b23 * b31)), m3 = fma_(b21, b32, -(b22 * b31));
+            const T minor = fma_(b13, m3, fma_(b11, m1, -(b12 * m2)));
+            cof = csign * minor;
+            // positive definite <=> the nested principal minors {3}, {2,3}, {1,2,3}, {0,1,2,3} are
+            // positive: lane (0, 0) has the first three at hand
+            pd = b33 > T(0) && m1 > T(0) && minor > T(0);
         }
-        const T qg = sh[g * 16 + ci]; // Qux[g][ci] (ci < 12), Quu[g][ci - 12] (ci >= 12)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        solve_quu4_fast<T>(Quu, rhs, bad); // k = -Quu^-1 Qu, K[:, ci] = -Quu^-1 Qux[:, ci]
-        const T kg = g == 0 ? rhs[0][1] : g == 1 ? rhs[1][1] : g == 2 ? rhs[2][1] : rhs[3][1]; // K[g][ci]
-        const T kc = cu == 0 ? rhs[0][0] : cu == 1 ? rhs[1][0] : cu == 2 ? rhs[2][0] : rhs[3][0]; // k[cu]
-        if (gain_on) *(T *)(out + ogain) = isx ? kg : kc;
+        T det = a_ij * cof;
+        det += __shfl_xor(det, 16);
+        det += __shfl_xor(det, 32);
+        bad = bad || __ballot(lane == 0 && !(pd && det > T(0))) != 0ull;
+        const T inv_e = cof * fast_rcp(det); // (Quu^-1)[ci][g] in the lanes ci < 4
+        // [K | k] = -Quu^-1 [Qux | Qu] as one more product: this lane supplies entry (g, ci) of the
+        // right factor, Qux[g][ci] (state lanes; taken from G[ci][12 + g], which this lane holds: G is
+        // symmetric up to the rounding of Vxx) or Qu[g] (the lane of index 12), and gets row g of
+        // column ci of the result in register 0.
+        const T qug = __shfl(qv, MF::tau(NX + g)); // Qu[g]
+        const T qg = TG[3];
+        acc R = {T(0), T(0), T(0), T(0)};
+        R = MF::run(inv_e, ci == NX ? qug : qg, R);
+        const T kg = -R[0]; // K[g][ci] (ci < 12), k[g] (ci == 12)
+        if (gain_on) *(T *)(out + ogain) = kg;
         // Vx = Qx + K' Qu ; Vxx = Qxx + K' Qux (ilqr.py:104-105)
-        T nvx = qv;
-#pragma unroll
-        for (int q = 0; q < NU; ++q) nvx = fma_(rhs[q][1], Qu[q], nvx);
-        vx = nvx; // (the lanes of the inputs are never asked for theirs)
+        T kq = kg * qug;
+        kq += __shfl_xor(kq, 16);
+        kq += __shfl_xor(kq, 32);
+        vx = qv + kq; // (the lanes of the inputs are never asked for theirs)
         TG = MF::run(qg, kg, TG);
 #pragma unroll
         for (int r = 0; r < 3; ++r) Vt[r] = TG[r];
     };
-    // Iteration i handles step t = T1 - 1 - i from ring slot i mod D and leaves its gains in output
-    // image i mod 2.  A direct load is ordered before a read of its data only by the loading wave's
-    // counted wait followed by a barrier, so per iteration: wait until this wave's piece of step t
-    // has landed, meet (every piece has landed; every wave is done with the previous step and its
-    // gains are in the image), refill the ring slot, write out the image of the previous step, compute.
+    // Group m handles the steps t = T1 - 1 - (m S + u), u = 0 .. S - 1, from ring slot m mod D and
+    // leaves their gains in the output images of parity m mod 2.  A direct load is ordered before a
+    // read of its data only by the loading wave's counted wait followed by a barrier, so per group:
+    // wait until this wave's pieces of the group have landed, meet (every piece has landed; every
+    // wave is done with the previous group and its gains are in the images), refill the ring slot,
+    // write out the images of the previous group, compute.
+    const int NM = (T1 + S - 1) / S;
+    auto stage_group = [&](int m, int slot) {
 #pragma unroll
-    for (int s = 0; s < D - 1; ++s) stage(T1 - 1 - s > 0 ? T1 - 1 - s : 0, s);
-    for (int ib = 0; ib < T1; ib += D) {
+        for (int u = 0; u < S; ++u) {
+            const int t = T1 - 1 - (m * S + u);
+            stage(t > 0 ? t : 0, slot * S + u);
+        }
+    };
+    auto write_group = [&](int m) {
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+            const int t = T1 - 1 - (m * S + u);
+            if (t >= 0) write_out(t, (m & 1) * S + u);
+        }
+    };
+#pragma unroll
+    for (int m = 0; m < D - 1; ++m) stage_group(m, m);
+    for (int mb = 0; mb < NM; mb += D) {
 #pragma unroll
         for (int s = 0; s < D; ++s) {
-            const int i = ib + s, t = T1 - 1 - i;
-            if (t < 0) break; // uniform over the workgroup
-            if (w < NLOAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 2) : "memory");
+            const int m = mb + s;
+            if (m >= NM) break; // uniform over the workgroup
+            if (w < NLOAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * S) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            stage(t - (D - 1) > 0 ? t - (D - 1) : 0, (s + D - 1) % D);
-            if (i > 0) write_out(t + 1, (s + 1) & 1);
-            if (act) one_step(lds + s * IN_BYTES, lds + OFF_OUT + (s & 1) * OUT_BYTES);
+            stage_group(m + D - 1, (s + D - 1) % D);
+            if (m > 0) write_group(m - 1);
+            if (act) {
+#pragma unroll
+                for (int u = 0; u < S; ++u) {
+                    if (T1 - 1 - (m * S + u) < 0) break;
+                    one_step(lds + (s * S + u) * IN_BYTES, lds + OFF_OUT + ((s & 1) * S + u) * OUT_BYTES);
+                }
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    write_out(0, (T1 - 1) & 1);
+    write_group(NM - 1);
     if (act && lane == 0) p.redo[o] = bad ? 1 : 0;
 }
 
@@ -2098,11 +2150,11 @@ template <typename T> __global__ __launch_bounds__(1024) void ltv12x4_evaluate_m
     using St = LtvStage<T>;
     using MF = Mfma4<T>;
     using acc = typename MF::acc;
-    constexpr int NX = 12, NU = 4, D = LTV_RING, ES = (int)sizeof(T), GPR = St::GPR, PPG = St::PPG;
+    constexpr int NX = 12, NU = 4, D = LTV_RING, S = LTV_EVALUATE_GROUP, ES = (int)sizeof(T), GPR = St::GPR, PPG = St::PPG;
     constexpr int ROWS = 80; // rows of a step: K 0..47, k 48..51, x 52..63, u 64..67, xref 68..79
     constexpr int AGR = NX * NX * ES / 16, TBL = NX * (NX + NU) * ES / 16;
     constexpr int NLOAD = (ROWS * GPR + TBL + 63) / 64, CHUNK = NLOAD * 1024;
-    __shared__ __attribute__((aligned(16))) unsigned char ring[D * CHUNK];
+    __shared__ __attribute__((aligned(16))) unsigned char ring[D * S * CHUNK];
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const int ci = MF::tau(c);                                      // the row of a left factor this lane supplies
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave = problem of the workgroup
@@ -2194,22 +2246,37 @@ template <typename T> __global__ __launch_bounds__(1024) void ltv12x4_evaluate_m
 #pragma unroll
         for (int q = 0; q < 3; ++q) z[q] = Xn[q];
     };
-    // Step t is computed from ring slot t mod D while the steps t + 1 .. t + D - 1 are on their way.
-    // A direct load is ordered before a read of its data only by the loading wave's counted wait
-    // followed by a barrier, so per step: wait until this wave's piece of step t has landed, meet
-    // (every piece has landed, and every wave is done with step t - 1), refill the slot step t - 1
+    // The steps move through the ring in groups of S: group m (steps m S .. m S + S - 1) is computed
+    // from ring slot m mod D while the groups m + 1 .. m + D - 1 are on their way.  A direct load is
+    // ordered before a read of its data only by the loading wave's counted wait followed by a
+    // barrier, so per group: wait until this wave's pieces of the group have landed, meet (every
+    // piece has landed, and every wave is done with the previous group), refill the slot that group
     // used, compute.
+    const int NM = (T1 + S - 1) / S;
+    auto stage_group = [&](int m, int slot) {
 #pragma unroll
-    for (int s = 0; s < D - 1; ++s) stage(s < T1 ? s : T1 - 1, s);
-    for (int tb = 0; tb < T1; tb += D) {
+        for (int u = 0; u < S; ++u) {
+            const int t = m * S + u;
+            stage(t < T1 ? t : T1 - 1, slot * S + u);
+        }
+    };
+#pragma unroll
+    for (int m = 0; m < D - 1; ++m) stage_group(m, m);
+    for (int mb = 0; mb < NM; mb += D) {
 #pragma unroll
         for (int s = 0; s < D; ++s) {
-            const int t = tb + s;
-            if (t >= T1) break; // uniform over the workgroup
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 2) : "memory");
+            const int m = mb + s;
+            if (m >= NM) break; // uniform over the workgroup
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * S) : "memory");
             __builtin_amdgcn_s_barrier();
-            stage(t + D - 1 < T1 ? t + D - 1 : T1 - 1, (s + D - 1) % D);
-            if (act) one_step(ring + s * CHUNK);
+            stage_group(m + D - 1, (s + D - 1) % D);
+            if (act) {
+#pragma unroll
+                for (int u = 0; u < S; ++u) {
+                    if (m * S + u >= T1) break;
+                    one_step(ring + (s * S + u) * CHUNK);
+                }
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
