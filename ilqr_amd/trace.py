@@ -135,7 +135,9 @@ class Sym:
                          "int()): it is not straight-line arithmetic and cannot be traced; "
                          "derive it from systems.DeviceSystem and write the device snippets by hand")
 
-    __lt__ = __le__ = __gt__ = __ge__ = __bool__ = __float__ = __int__ = __index__ = _refuse
+    # (== and != too: the default identity comparison would answer False / True as a plain bool and
+    # silently record one branch of a guard such as ``if v == 0.0``)
+    __lt__ = __le__ = __gt__ = __ge__ = __eq__ = __ne__ = __bool__ = __float__ = __int__ = __index__ = _refuse
     __hash__ = object.__hash__
 
 
@@ -266,12 +268,14 @@ def _recording_numpy():
         return wrapped
 
     def converter(fn):
-        def wrapped(obj, *a, **k):
-            dt = k.get("dtype", a[0] if a else None)
+        def wrapped(*a, **k):
+            # the converted object is the first positional argument or numpy's keyword for it
+            obj = a[0] if a else k.get("object", k.get("a"))
+            dt = k.get("dtype", a[1] if len(a) > 1 else None)
             if threading.get_ident() == owner and _holds_sym(obj) and (dt is None or dt in _FLOAT_DTYPES or dt is object):
                 k.pop("dtype", None)
-                return fn(obj, *a[1:], dtype=object, **k)
-            return fn(obj, *a, **k)
+                return fn(*a[:1], *a[2:], dtype=object, **k)
+            return fn(*a, **k)
         return wrapped
 
     with _patch_lock:

@@ -98,6 +98,38 @@ class _FloatCall(_Branchy):
         return np.array([x[0] + float(x[1]) * self.dt, x[1] + u[0] * self.dt])
 
 
+class _EqualityGuard(_Branchy):
+    """a guard on equality: random check points would never hit the equal branch"""
+
+    def model_f(self, x, u):
+        v = x[1] if x[1] == 0.0 else x[1] * 1.0
+        return np.array([x[0] + v * self.dt, x[1] + u[0] * self.dt])
+
+
+class _NotEqualGuard(_Branchy):
+    def model_f(self, x, u):
+        g = 1.0 if x[0] != 0 else 0.0
+        return np.array([x[0] + g * x[1] * self.dt, x[1] + u[0] * self.dt])
+
+
+class _KeywordConversion(System):
+    """np.array(object=...) and np.asarray(a=...) by keyword"""
+
+    def __init__(self):
+        super().__init__(2, 1)
+        self.dt = 0.1
+
+    def model_f(self, x, u):
+        xs = np.asarray(a=x, dtype=float)
+        return np.array(object=[xs[0] + xs[1] * self.dt, xs[1] + u[0] * self.dt], dtype=float)
+
+    def compute_df_dx(self, x, u):
+        return np.array(object=[[1.0, self.dt], [0.0, 1.0]])
+
+    def compute_df_du(self, x, u):
+        return np.array([[0.0], [self.dt]])
+
+
 class _FillIn(System):
     """arrays allocated with numpy and filled by item assignment"""
 
@@ -146,7 +178,14 @@ def test_allocation_and_coercion_idioms_are_recorded():
     assert np.asarray([1, 2], dtype=float).dtype == np.float64
 
 
+def test_keyword_conversions_are_recorded():
+    t = trace.trace_system(_KeywordConversion())
+    assert "xn[0] =" in t["step"] and t["fx_pattern"].tolist() == [[2, 1], [0, 2]]
+    assert np.array(object=[1, 2], dtype=float).dtype == np.float64
+
+
 @pytest.mark.parametrize("cls,needle", [(_Branchy, "compares or converts"), (_FloatCall, "compares or converts"),
+                                        (_EqualityGuard, "compares or converts"), (_NotEqualGuard, "compares or converts"),
                                         (_Stateful, "does not compute the same values"),
                                         (_WrongShape, "returned 4 values, expected 2")])
 def test_untraceable_models_are_refused_with_a_reason(cls, needle):
