@@ -59,11 +59,14 @@ def resolve_model(system, dtype, constraint_mode=_lib.CONSTR_NONE):
     holds as a literal yields another model; compiled libraries are cached by content."""
     np_dtype = _np_dtype(dtype)
     model_id = getattr(system, "device_model_id", None)
-    if model_id is not None and _shipped_dynamics(system):
-        return int(model_id)
     diag = all(np.count_nonzero(W - np.diag(np.diagonal(W))) == 0
                for W in (np.asarray(system.Q, dtype=float), np.asarray(system.R, dtype=float),
                          np.asarray(system.Q_f, dtype=float)))
+    if model_id is not None and _shipped_dynamics(system):
+        from . import systems
+        if isinstance(system, systems.LTVSystem) and not system.builtin_kernels(diag):
+            return int(system.device_model(np_dtype, diag))   # a table model of another size, or dense weights
+        return int(model_id)
     if getattr(system, "device_step", None) is not None and hasattr(system, "device_model"):
         return int(system.device_model(np_dtype, diag))
     from . import trace
@@ -162,8 +165,10 @@ class DeviceProblem:
                 self.centers = torch.zeros(Bp * N * 2, dtype=td, device=dev)
                 self.radius = torch.ones(Bp * N, dtype=td, device=dev)
             self.ltv_A = self.ltv_B = None
-            if getattr(system, "device_tables", None) is not None:  # parameter tables of a run-time compiled model
+            if d.model != 3 and getattr(system, "device_tables", None) is not None:  # tables of a run-time compiled model
                 ta, tb = system.device_tables
+                if hasattr(system, "builtin_kernels") and (np.shape(ta) != (N - 1, n, n) or np.shape(tb) != (N - 1, n, m)):
+                    raise ValueError("LTVSystem tables must be A (N-1, n, n) and B (N-1, n, m)")
                 self.ltv_A = torch.from_numpy(np.ascontiguousarray(ta, dtype=self.np_dtype)).to(dev)
                 self.ltv_B = torch.from_numpy(np.ascontiguousarray(tb, dtype=self.np_dtype)).to(dev)
             if d.model == 3:  # table-driven LTV: the tables are shared by the whole batch

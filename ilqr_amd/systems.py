@@ -171,6 +171,41 @@ class LTVSystem(System):
         self.A, self.B = A, B
         self.dt = dt
 
+    # The kernels built into the library serve n = 12, m = 4 with diagonal weights (matrix unit).
+    # Any other size, or dense weights, gets the same table model compiled at run time for the
+    # lane-per-problem kernels, once per (n, m, element type, diagonal or dense weights).
+    _STEP = ("const T *A_ = par_a + (size_t)t * NX * NX, *B_ = par_b + (size_t)t * NX * NU;\n"
+             "_Pragma(\"unroll\") for (int i = 0; i < NX; ++i) {\n"
+             "    T s = A_[i * NX] * x[0];\n"
+             "    _Pragma(\"unroll\") for (int j = 1; j < NX; ++j) s = fma_(A_[i * NX + j], x[j], s);\n"
+             "    _Pragma(\"unroll\") for (int j = 0; j < NU; ++j) s = fma_(B_[i * NU + j], u[j], s);\n"
+             "    xn[i] = s;\n"
+             "}")
+    _JAC = ("const T *A_ = par_a + (size_t)t * NX * NX, *B_ = par_b + (size_t)t * NX * NU;\n"
+            "_Pragma(\"unroll\") for (int i = 0; i < NX; ++i) {\n"
+            "    _Pragma(\"unroll\") for (int j = 0; j < NX; ++j) fx[i][j] = A_[i * NX + j];\n"
+            "    _Pragma(\"unroll\") for (int j = 0; j < NU; ++j) fu[i][j] = B_[i * NU + j];\n"
+            "}")
+    _compiled = {}
+
+    @property
+    def device_tables(self):
+        return (self.A, self.B)
+
+    def builtin_kernels(self, diag):
+        """True if the library's own n = 12, m = 4 kernels serve this system."""
+        return self.state_size == 12 and self.control_size == 4 and bool(diag)
+
+    def device_model(self, dtype=np.float64, diag=True, verbose=False):
+        """Model id of the run-time compiled table model of this size."""
+        from . import jit
+        key = (self.state_size, self.control_size, "f64" if np.dtype(dtype) == np.float64 else "f32", bool(diag))
+        if key not in LTVSystem._compiled:
+            src = jit.model_source(self.state_size, self.control_size, self._STEP, self._JAC, None, None, False,
+                                   variants=(key[2:],))
+            LTVSystem._compiled[key] = jit.load_model(jit.build_model(src, verbose=verbose))
+        return LTVSystem._compiled[key]
+
     def model_f(self, x, u, t=0):
         return self.A[t] @ np.asarray(x, dtype=float) + self.B[t] @ np.asarray(u, dtype=float)
 

@@ -610,6 +610,41 @@ def test_ltv12x4_indefinite_quu_uses_the_fallback_launch(ilqr_cls, oracle):
         assert nrm(opt.K[b], Ko) <= 1e-9 and nrm(opt.k[b][:, :, 0], ko) <= 1e-9
 
 
+@pytest.mark.parametrize("n,m,dense", [(6, 2, False), (12, 4, True)])
+def test_ltv_of_other_sizes_and_dense_weights(ilqr_cls, oracle, n, m, dense):
+    """The library's own table-model kernels are built for n = 12, m = 4 and diagonal weights; any
+    other LTVSystem is served by the same model compiled at run time for the lane-per-problem
+    kernels.  Checker: the oracle's dense statement of ilqr.py (no reference counterpart)."""
+    from ilqr_amd import problems, systems
+    N, B = 60, 70
+    A, Bm, Q, R = problems.ltv_system(N=N, n=n, m=m)
+    if dense:
+        rng = np.random.default_rng(5)
+        V = np.linalg.qr(rng.standard_normal((n, n)))[0]
+        Q = V @ Q @ V.T                                    # same spectrum, not diagonal
+    s = systems.LTVSystem(A, Bm, dt=0.05)
+    s.set_cost(Q, R)
+    s.set_control_limit([-2.0] * m, [2.0] * m)
+    p = problems.ltv_batch(B, N, n=n, m=m)
+    opt = ilqr_cls(s, p["target_states"], s.dt, history=True)
+    opt.inputs, opt.states = p["init_inputs"].copy(), p["init_states"].copy()
+    dev = opt.upload()
+    assert dev.desc.model >= 16                            # a run-time compiled model, not the built-in id
+    dev.initial_cost()
+    dev.backward()
+    d = oracle.make_desc(s, N)
+    for b in (0, 69):
+        Ko, ko, rc = oracle.backward(d, np.ascontiguousarray(p["target_states"][b]), p["init_states"][b].copy(),
+                                     p["init_inputs"][b].copy())
+        assert rc == 0
+        assert nrm(dev.download_K()[b], Ko) <= 1e-11 and nrm(dev.download_k()[b][:, :, 0], ko) <= 1e-11
+    opt()
+    r = oracle.solve_batch(d, p["target_states"], p["init_states"].copy(), p["init_inputs"].copy())
+    assert np.all(opt.status == 0)
+    assert np.abs(opt.cost_history[:, 0] - r["hist_cost"][:, 0]).max() <= 1e-9 * np.abs(r["hist_cost"][:, 0]).max()
+    assert np.abs(opt.min_cost - r["min_cost"]).max() <= 1e-9 * np.abs(r["min_cost"]).max()
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_ltv12x4_unselected_neighbours_keep_their_gains(ilqr_cls, dtype):
     """The matrix-unit backward kernel handles 16 neighbouring problems per workgroup and writes
