@@ -101,11 +101,17 @@ def test_auto_choices_and_workspace_of_a_handle():
     lib.ilqr_destroy(h)
     rc, h = _create(_desc(B=4096, N=200))
     assert rc == 0 and mapping(h) == (16, 1)         # small batch: all step sizes in one stage, a lane each
-    assert lib.ilqr_workspace_bytes(h) < 4096 * 200 * 4 * 8   # below the compaction threshold
+    # below the compaction threshold: no working sets, but the sine/cosine pairs of the committed
+    # trajectory and the candidates' states at the start of every 32-step segment
+    auto = lib.ilqr_workspace_bytes(h)
+    assert 4096 * (199 * 2 + 7 * 16 * 4) * 8 <= auto < 4096 * (199 * 2 + 7 * 16 * 4) * 8 + 4096 * 200 * 8
     for fn in (lib.ilqr_repack, lib.ilqr_unpack, lib.ilqr_initial_cost, lib.ilqr_forward_evaluate):
         assert fn(h, None) == -3
     assert lib.ilqr_forward_evaluate_stage(h, 1, None) == -3
     assert lib.ilqr_shift(h, 1, None, None) == -3
+    lib.ilqr_destroy(h)
+    rc, h = _create(_desc(B=4096, N=200, trig_cache=-1, segment_commit=-1))
+    assert rc == 0 and lib.ilqr_workspace_bytes(h) < 4096 * 200 * 4 * 8   # neither of them: per-problem scalars only
     lib.ilqr_destroy(h)
     for B, want in ((8192, (8, 2)), (16384, (4, 4)), (32768, (2, 4))):
         rc, h = _create(_desc(B=B, N=200))
