@@ -198,7 +198,9 @@ template <typename T, int NX, int NU> static Params<T, NX, NU> make_params(const
     p.N = d.N;
     p.n_alphas = c.n_alphas;
     p.select_converged = c.select_converged ? 1 : 0;
-    p.carried = c.select_converged ? (const int32_t *)((char *)b.work + work_layout(d, true).carried) : nullptr;
+    // (indexed like the other per-problem arrays: by global problem index through the slot map, by
+    // the index within the part otherwise)
+    p.carried = c.select_converged ? flat((const int32_t *)((char *)b.work + work_layout(d, true).carried)) : nullptr;
     p.slots_lo = -1;
     p.slots_hi = 0x7fffffff;
     p.dt = (T)d.dt;

@@ -610,6 +610,52 @@ def test_ltv12x4_indefinite_quu_uses_the_fallback_launch(ilqr_cls, oracle):
         assert nrm(opt.K[b], Ko) <= 1e-9 and nrm(opt.k[b][:, :, 0], ko) <= 1e-9
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_ltv12x4_scheduling_does_not_change_a_bit(ilqr_cls, dtype):
+    """The matrix-unit kernels of the n = 12 model handle 16 problems per workgroup (backward pass,
+    line search) or per wave (commit); which problems share one, where a problem sits in its tile
+    and whether the active ones were repacked is pure scheduling: compaction, streams and ragged
+    shards must give the bits of the plain run.  Odd number of time steps, ragged batch."""
+    from ilqr_amd import problems
+    N, B = 48, 150
+    s = ltv_setup(N)
+    p = problems.ltv_batch(B, N)
+
+    def solve(sl=slice(None), **kw):
+        opt = ilqr_cls(s, p["target_states"][sl], s.dt, history=True, dtype=dtype, **kw)
+        opt.inputs, opt.states = p["init_inputs"][sl].copy(), p["init_states"][sl].copy()
+        opt.maxIter = 12
+        opt()
+        return opt
+
+    ref = solve(repack_every=-1)
+    assert len(set(ref.iterations.tolist())) > 1             # problems leave the active set at different times
+    for kw in (dict(repack_every=1), dict(repack_every=2, n_streams=2), dict(repack_every=-1, n_streams=3)):
+        o = solve(**kw)
+        for key in ("states", "inputs", "min_cost", "iterations", "converge", "status", "K", "k"):
+            assert np.array_equal(getattr(o, key), getattr(ref, key)), (kw, key)
+        assert np.array_equal(o.alpha_history, ref.alpha_history)
+    a, b = solve(slice(0, 77), repack_every=-1), solve(slice(77, B), repack_every=-1)
+    for key in ("states", "inputs", "min_cost", "iterations", "converge", "K", "k"):
+        assert np.array_equal(np.concatenate([getattr(a, key), getattr(b, key)]), getattr(ref, key)), key
+
+
+def test_ltv12x4_shortest_horizons(ilqr_cls, oracle):
+    """Horizons shorter than the staging ring of the matrix-unit kernels (one, two, five time steps)."""
+    from ilqr_amd import problems
+    for N in (2, 3, 6):
+        s = ltv_setup(N)
+        p = problems.ltv_batch(3, N)
+        opt = ilqr_cls(s, p["target_states"], s.dt, history=True)
+        opt.inputs, opt.states = p["init_inputs"].copy(), p["init_states"].copy()
+        opt()
+        xo, uo = p["init_states"].copy(), p["init_inputs"].copy()          # solved in place
+        r = oracle.solve_batch(oracle.make_desc(s, N), p["target_states"], xo, uo)
+        assert np.all(opt.status == 0)
+        assert np.abs(opt.min_cost - r["min_cost"]).max() <= 1e-9 * np.abs(r["min_cost"]).max()
+        assert nrm(opt.inputs, uo) <= 1e-8 and nrm(opt.states, xo) <= 1e-8
+
+
 @pytest.mark.parametrize("n,m,dense", [(6, 2, False), (12, 4, True)])
 def test_ltv_of_other_sizes_and_dense_weights(ilqr_cls, oracle, n, m, dense):
     """The library's own table-model kernels are built for n = 12, m = 4 and diagonal weights; any
