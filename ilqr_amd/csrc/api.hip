@@ -297,6 +297,14 @@ int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
             // with a tile per SIMD or more, six candidates in the first stage are the better split
             // (the accepted step is below index 6 in about 95 % of the line searches)
             if (L == 1 && na > 8) A = 6;
+            // Eight step sizes or fewer (cilqr.py:41) up to 16384 problems: a lane per candidate.  These
+            // solves run up to 100 iterations, most of them for a few stragglers, where only the length
+            // of a lane's serial rollout counts (measured at 16384 problems with box QP and barrier:
+            // 55.2 -> 49.7 ms per solve)
+            if (na <= 8 && d.B <= 16384) {
+                L = 8;
+                A = 1;
+            }
             // Up to 16384 problems every kernel is bound by the latency of one serial rollout, not by
             // throughput, and the second stage costs a whole rollout for a few problems: sixteen
             // candidates in a single stage are faster (measured at 4096 / 8192 / 16384 problems:
@@ -356,7 +364,9 @@ int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
     // chip idle during the sequential commit); needs a single-stage line search with four or more
     // lanes per problem (the launch tables check that), no compaction, one part.
     h->seg = d.n <= 8 && h->repack_every == 0 && d.overlap_stages <= 0 && h->n_parts == 1 && L >= 4 && L * A >= na && na <= 16 &&
-             (d.segment_commit > 0 || (d.segment_commit == 0 && d.B <= 8192)); // (16384: 14.6 against 14.5 ms, no gain)
+             (d.segment_commit > 0 || (d.segment_commit == 0 && d.B <= (d.constraint_mode != 0 ? 16384 : 8192)));
+    // (unconstrained at 16384: 14.6 against 14.5 ms, no gain; the constrained solver's long tail of
+    // iterations with few active problems gains at 16384 too: 58.0 -> 55.2 ms)
     h->ctx.seg = h->seg;
     // off unless asked for: beside the bandwidth-bound commit the latency-bound second stage runs
     // 2.5x slower and slows the commit down (measured: 34.8 -> 42.0 ms per solve at B = 65536)
