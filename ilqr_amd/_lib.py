@@ -32,7 +32,7 @@ class Desc(C.Structure):
         ("lanes_per_problem", C.c_int32), ("alphas_per_lane", C.c_int32),
         ("n_streams", C.c_int32), ("repack_every", C.c_int32), ("recompute_states", C.c_int32),
         ("overlap_stages", C.c_int32), ("trig_cache", C.c_int32),
-        ("segment_commit", C.c_int32), ("reserved3", C.c_int32),
+        ("segment_commit", C.c_int32), ("fused_solve", C.c_int32),
         ("dt", C.c_double), ("lm_parameter", C.c_double), ("alpha_floor", C.c_double),
         ("input_limit_lambda", C.c_double), ("barrier_mu", C.c_double),
         ("barrier_delta", C.c_double), ("vel_bounds", C.c_double * 2),

@@ -88,7 +88,7 @@ class DeviceProblem:
                  constraint_mode=_lib.CONSTR_NONE, input_limit_lambda=1e-4, barrier_mu=0.0,
                  barrier_delta=0.1, vel_bounds=(0.0, 0.0), lanes_per_problem=0, alphas_per_lane=0,
                  history=False, solver_limits=False, n_streams=0, repack_every=0, recompute_states=0,
-                 overlap_stages=0, model_id=None, limits=None, trig_cache=0, segment_commit=0):
+                 overlap_stages=0, model_id=None, limits=None, trig_cache=0, segment_commit=0, fused_solve=0):
         torch = _torch()
         if not torch.cuda.is_available():
             raise _lib.IlqrError("no GPU visible: the batched iLQR solve runs on the HIP device only")
@@ -119,6 +119,7 @@ class DeviceProblem:
         d.overlap_stages = int(overlap_stages)
         d.trig_cache = int(trig_cache)
         d.segment_commit = int(segment_commit)
+        d.fused_solve = int(fused_solve)
         d.dt = float(system.dt)
         d.lm_parameter = float(lm_parameter)
         d.alpha_floor = float(alpha_floor)
@@ -351,7 +352,7 @@ class BatchedSolverBase:
 
     def __init__(self, sys, target_states, dt, device=None, dtype=np.float64, history=False,
                  lanes_per_problem=0, alphas_per_lane=0, n_streams=0, repack_every=0, recompute_states=0,
-                 overlap_stages=0, trig_cache=0, segment_commit=0):
+                 overlap_stages=0, trig_cache=0, segment_commit=0, fused_solve=0):
         if not isinstance(sys, System) and not hasattr(sys, "state_size"):
             raise TypeError("sys must provide the systems.System interface")
         self.target_states = target_states
@@ -393,6 +394,7 @@ class BatchedSolverBase:
         self._overlap_stages = int(overlap_stages)
         self._trig_cache = int(trig_cache)
         self._segment_commit = int(segment_commit)
+        self._fused_solve = int(fused_solve)
         self._dev = None
         self._k_cache = self._K_cache = None
         self.cost_history = None
@@ -430,7 +432,7 @@ class BatchedSolverBase:
                 lanes_per_problem=self._mapping[0], alphas_per_lane=self._mapping[1],
                 n_streams=self._n_streams, repack_every=self._repack_every,
                 recompute_states=self._recompute_states, overlap_stages=self._overlap_stages,
-                trig_cache=self._trig_cache, segment_commit=self._segment_commit, model_id=self._model_id,
+                trig_cache=self._trig_cache, segment_commit=self._segment_commit, fused_solve=self._fused_solve, model_id=self._model_id,
                 **self._extra_desc())
             self._dev_key = key
         # maxIter may change between calls (the iteration count is an argument of ilqr_solve); only

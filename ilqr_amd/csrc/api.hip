@@ -34,6 +34,7 @@ struct ilqr_handle {
     int repack_every = 0;   // 0: no compaction
     bool trig = false;      // sine/cosine cache in `work` (HostCtx::trig)
     bool seg = false;       // candidate checkpoints in `work`, time-parallel commit (HostCtx::seg)
+    bool fused = false;     // ilqr_solve runs its iterations in one launch (solve_owned_kernel)
     // the phase calls (ilqr_backward ...) and the single-stream ilqr_solve work on the whole batch as
     // one part whose compaction state lives here, between calls
     PartState whole;
@@ -47,6 +48,13 @@ struct ilqr_handle {
 };
 
 static thread_local int g_last_hip_error = 0;
+
+// Batch sizes for which ilqr_solve chooses the single-launch solve by itself.  Measured (Car, N = 200,
+// ms per solve, launch per phase -> single launch): 4096 problems 7.35 -> 7.85, 8192: 9.81 -> 9.82,
+// 16384: 14.43 -> 13.78, 32768: 21.2 -> 24.1.  A workgroup's iteration is the same three serial sweeps
+// either way; what the single launch saves is the gaps and tails of 90 launches, what it costs is
+// shallower prefetching (its phases share one register budget).
+constexpr int FUSED_AUTO_MIN = 8193, FUSED_AUTO_MAX = 16384;
 
 // ---- scratch of ilqr_solve_static ---------------------------------------------------------------
 // One array per GPU, in the library's own device image, so that the entry point never allocates.
@@ -363,8 +371,12 @@ int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
     // Time-parallel commit: 0 = auto, for the same batch sizes (one lane per problem leaves most of the
     // chip idle during the sequential commit); needs a single-stage line search with four or more
     // lanes per problem (the launch tables check that), no compaction, one part.
-    h->seg = d.n <= 8 && h->repack_every == 0 && d.overlap_stages <= 0 && h->n_parts == 1 && L >= 4 && L * A >= na && na <= 16 &&
-             (d.segment_commit > 0 || (d.segment_commit == 0 && d.B <= (d.constraint_mode != 0 ? 16384 : 8192)));
+    const bool seg_ok = d.n <= 8 && h->repack_every == 0 && d.overlap_stages <= 0 && h->n_parts == 1 && L >= 4 && L * A >= na && na <= 16;
+    // One launch for the whole solve (solve_owned_kernel): 0 = auto.  It is built on the time-parallel
+    // commit, for unconstrained problems and the mappings with 16 candidates per round.
+    const bool fused_ok = seg_ok && ops->solve != nullptr && (d.constraint_mode & 3) == 0 && L * A == 16 && d.segment_commit >= 0;
+    h->fused = fused_ok && (d.fused_solve > 0 || (d.fused_solve == 0 && d.B >= FUSED_AUTO_MIN && d.B <= FUSED_AUTO_MAX));
+    h->seg = seg_ok && (h->fused || d.segment_commit > 0 || (d.segment_commit == 0 && d.B <= (d.constraint_mode != 0 ? 16384 : 8192)));
     // (unconstrained at 16384: 14.6 against 14.5 ms, no gain; the constrained solver's long tail of
     // iterations with few active problems gains at 16384 too: 58.0 -> 55.2 ms)
     h->ctx.seg = h->seg;
@@ -576,6 +588,10 @@ static int solve_impl(ilqr_handle *h, int32_t max_iter, void *work, bool compact
             forked = s + 1;
         }
         rc = hip_rc(h->ops->cost(part[s].ctx, 0, st[s]));
+    }
+    if (rc == ILQR_OK && np == 1 && h->fused && extras && part[0].ctx.seg) {
+        // all iterations in one launch; nothing to unpack (no compaction with this path)
+        return hip_rc(h->ops->solve(part[0].ctx, max_iter, st[0]));
     }
     // Launch order is iteration-major across parts.  The line search is arithmetic-bound, the
     // backward pass and the commit are bandwidth-bound; a token (an event chain) lets only one

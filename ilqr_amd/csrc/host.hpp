@@ -113,6 +113,9 @@ struct ModelOps {
     probe_fn probe;
     launch_fn rollout; // X[t+1] = f(X[t], U[t]) from X[0] (sqp.py:56-61)
     int trig_pairs;    // sine/cosine pairs the model shares between step and Jacobian (0: HostCtx::trig is ignored)
+    // `it` iterations of backward pass + line search + commit in ONE launch (solve_owned_kernel), for a context
+    // that runs the time-parallel commit (HostCtx::seg); hipErrorNotSupported if the combination is not built
+    launch_fn solve;
 };
 
 // What a separately compiled model library (ilqr_load_model) hands to this one.  `abi` must equal
@@ -127,7 +130,7 @@ struct PluginInfo {
     const ModelOps *(*ops)(int dtype, bool diag);
     const SqpOps *(*sqp)(int dtype); // sequential-QP kernels for this model, or a function returning null
 };
-constexpr int32_t PLUGIN_ABI_VERSION = 4;
+constexpr int32_t PLUGIN_ABI_VERSION = 5;
 static inline int32_t plugin_abi() {
     return (int32_t)(PLUGIN_ABI_VERSION * 1000003u + sizeof(HostCtx) * 31u + sizeof(ilqr_desc) * 7u + sizeof(ilqr_buffers));
 }
@@ -525,8 +528,29 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
         hipLaunchKernelGGL((rollout_kernel<T, M>), dim3((c.count + 63) / 64), dim3(64), 0, s, p);
         return hipGetLastError();
     }
+    // The whole iteration loop in one launch (solve_owned_kernel): unconstrained problems, the
+    // single-stage mappings with 16 candidates per round, time-parallel commit.
+    template <int L, int A> static hipError_t solve_la(const HostCtx &c, int max_iter, hipStream_t s) {
+        auto p = make_params<T, NX, NU>(c);
+        constexpr int G = 256 / L;
+        hipLaunchKernelGGL((solve_owned_kernel<T, M, DIAG, 0, L, A, 2>), dim3((c.count + G - 1) / G), dim3(256), 0, s, p, max_iter,
+                           commit_segments(c.d), c.d.recompute_states >= 0 ? 1 : 0);
+        return hipGetLastError();
+    }
+    static hipError_t solve(const HostCtx &c, int max_iter, hipStream_t s) {
+        if constexpr (M::NX <= 8) {
+            if (!use_seg(c) || (c.d.constraint_mode & 3) != 0 || c.reroll) return hipErrorNotSupported;
+            switch (c.L * 100 + c.A) {
+            case 1601: return solve_la<16, 1>(c, max_iter, s);
+            case 802: return solve_la<8, 2>(c, max_iter, s);
+            case 404: return solve_la<4, 4>(c, max_iter, s);
+            default: return hipErrorNotSupported;
+            }
+        }
+        return hipErrorNotSupported;
+    }
     static const ModelOps *table() {
-        static const ModelOps ops = {&cost, &backward, &evaluate, &commit, &probe, &rollout, trig_pairs<M>::value};
+        static const ModelOps ops = {&cost, &backward, &evaluate, &commit, &probe, &rollout, trig_pairs<M>::value, &solve};
         return &ops;
     }
 };

@@ -860,10 +860,10 @@ __device__ __forceinline__ int backward_sweep(const P &p, const T *Xt, const T *
     return status;
 }
 
-template <typename T, class M, bool DIAG, int CONSTR, int PF, bool TC = false>
-__global__ __launch_bounds__(64) void backward_kernel(Params<T, M::NX, M::NU> p) {
+// The backward pass of the problem in slot b0 (one lane per problem).
+template <typename T, class M, bool DIAG, int CONSTR, int PF, bool TC = false, class P>
+__device__ __forceinline__ void backward_body(const P &p, int b0) {
     constexpr int NX = M::NX, NU = M::NU;
-    const int b0 = blockIdx.x * 64 + threadIdx.x;
     const int nsl = slot_count(p);
     if (nsl <= 0) return;
     const bool valid = b0 < nsl;
@@ -897,6 +897,11 @@ __global__ __launch_bounds__(64) void backward_kernel(Params<T, M::NX, M::NU> p)
         status = redo ? status2 : status;
     }
     if (active && status != 0 && p.status) p.status[o] |= status;
+}
+
+template <typename T, class M, bool DIAG, int CONSTR, int PF, bool TC = false>
+__global__ __launch_bounds__(64) void backward_kernel(Params<T, M::NX, M::NU> p) {
+    backward_body<T, M, DIAG, CONSTR, PF, TC>(p, blockIdx.x * 64 + threadIdx.x);
 }
 
 // ---------------------------------------------------------------- backward pass, n = 12, m = 4, fp64
@@ -1736,12 +1741,11 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
 // them while candidates remain is appended to a device-side list; stage two
 // (evaluate_listed_kernel) walks that list with the remaining candidates.  Candidates are still
 // examined in increasing index order, so the result is that of the serial search.
-template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool REROLL, bool TC = false, bool CKPT = false>
-__global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T, M::NX, M::NU> p, int end) {
+// (body of evaluate_kernel: the work of wave number `wave` of the launch)
+template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool REROLL, bool TC = false, bool CKPT = false, class P>
+__device__ __forceinline__ void evaluate_body(const P &p, int end, int wave, int lane) {
     constexpr int NX = M::NX, NU = M::NU;
     constexpr int PPW = 64 / L; // problems per wave
-    const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int pl = lane / L, al = lane % L;
     const int g = wave * PPW + pl;
     const int nsl = slot_count(p);
@@ -1807,6 +1811,11 @@ __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T,
         p.Jtry[o] = best_cost;
         p.slow_trig[o] = (p.slow_trig[o] & 6) | (pbad ? 1 : 0);
     }
+}
+
+template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool REROLL, bool TC = false, bool CKPT = false>
+__global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T, M::NX, M::NU> p, int end) {
+    evaluate_body<T, M, DIAG, BARRIER, L, A, REROLL, TC, CKPT>(p, end, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
 // ---------------------------------------------------------------- evaluate, stage two
@@ -2618,10 +2627,10 @@ template <typename T> __global__ __launch_bounds__(256) void ltv12x4_commit_mfma
 // checkpoint; the last segment also the terminal state), and reads the previous states of the
 // same steps before it overwrites them: no row is shared between waves.
 // The wave of segment 0 also does the per-problem bookkeeping of commit_kernel.
-template <typename T, class M, bool FAST, bool TC, class P>
+template <typename T, class M, bool FAST, bool TC, int RING = 4, class P>
 __device__ __forceinline__ void commit_segment_sweep(const P &p, T *Xt, T *Ut, const T *Kp, const T *kp, T *SCt, T alpha, const T (&xs)[M::NX],
                                                      int t0, int t1, bool store, bool first) {
-    constexpr int NX = M::NX, NU = M::NU, S = COMMIT_SEG, RING = 4;
+    constexpr int NX = M::NX, NU = M::NU, S = COMMIT_SEG;
     static_assert(S % RING == 0, "the segment length must be a multiple of the prefetch ring");
     const int T1 = p.N - 1;
     struct Row {
@@ -2632,15 +2641,20 @@ __device__ __forceinline__ void commit_segment_sweep(const P &p, T *Xt, T *Ut, c
     // the end of the segment its last row is fetched again)
     auto load_row = [&](int tt, Row &r) {
         const int t = tt < t1 ? tt : t1 - 1;
+        // one row pointer per array and compile-time offsets from it: the time index may differ from
+        // lane to lane (solve_owned_kernel), and an index expression per value would then take an
+        // address register pair per load
+        const T *kr = kp + (size_t)t * (NU * TILE), *ur = Ut + (size_t)t * (NU * TILE);
+        const T *Kr = Kp + (size_t)t * (NU * NX * TILE), *xr = Xt + (size_t)t * (NX * TILE);
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-            r.k[i] = kp[(t * NU + i) * TILE];
-            r.up[i] = Ut[(t * NU + i) * TILE];
+            r.k[i] = kr[i * TILE];
+            r.up[i] = ur[i * TILE];
 #pragma unroll
-            for (int j = 0; j < NX; ++j) r.K[i][j] = Kp[((t * NU + i) * NX + j) * TILE];
+            for (int j = 0; j < NX; ++j) r.K[i][j] = Kr[(i * NX + j) * TILE];
         }
 #pragma unroll
-        for (int i = 0; i < NX; ++i) r.xp[i] = Xt[(t * NX + i) * TILE];
+        for (int i = 0; i < NX; ++i) r.xp[i] = xr[i * TILE];
     };
     T x[NX];
 #pragma unroll
@@ -2665,25 +2679,30 @@ __device__ __forceinline__ void commit_segment_sweep(const P &p, T *Xt, T *Ut, c
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = xn[i];
         if (store && t < t1) {
+            T *uw = Ut + (size_t)t * (NU * TILE);
 #pragma unroll
-            for (int i = 0; i < NU; ++i) Ut[(t * NU + i) * TILE] = un[i];
+            for (int i = 0; i < NU; ++i) uw[i * TILE] = un[i];
             if (TC) {
-                SCt[(t * 2 + 0) * TILE] = sn;
-                SCt[(t * 2 + 1) * TILE] = cn;
+                T *sw = SCt + (size_t)t * (2 * TILE);
+                sw[0] = sn;
+                sw[TILE] = cn;
             }
             if (t + 1 < t1 || t + 1 == T1) { // the next segment writes its own first state
+                T *xw = Xt + (size_t)(t + 1) * (NX * TILE);
 #pragma unroll
-                for (int i = 0; i < NX; ++i) Xt[((t + 1) * NX + i) * TILE] = xn[i];
+                for (int i = 0; i < NX; ++i) xw[i * TILE] = xn[i];
             }
         }
     }
 }
 
-template <typename T, class M, bool TC>
-__global__ __launch_bounds__(64) void commit_segments_kernel(Params<T, M::NX, M::NU> p, int it, int nseg) {
+// (body of commit_segments_kernel: segment `seg` of the problem b0, one lane each)
+// RING: rows in flight per lane (with a segment per lane instead of per wave the addresses are per lane
+// too, and four rows no longer fit the register file beside them)
+template <typename T, class M, bool TC, int RING = 4, class P>
+__device__ __forceinline__ void commit_segments_body(const P &p, int it, int nseg, int b0, int seg) {
     constexpr int NX = M::NX, NU = M::NU;
-    const int tile = blockIdx.x / nseg, seg = blockIdx.x % nseg, ln = threadIdx.x;
-    const int b0 = tile * 64 + ln;
+    const int tile = b0 >> 6, ln = b0 & 63;
     const bool valid = b0 < p.B;
     const int b = valid ? b0 : p.B - 1;
     // (the wave of segment 0 may already have marked a problem without an accepted step as
@@ -2729,8 +2748,83 @@ __global__ __launch_bounds__(64) void commit_segments_kernel(Params<T, M::NX, M:
         xs[i] = seg == 0 ? Xt[i * TILE] : CKp[(size_t)((seg * CK_CANDIDATES + cand) * NX + i) * TILE];
     // per problem: the fast sweep writes nothing for a problem that needs the library sine/cosine
     // and the second sweep (rare) writes only those, as in commit_kernel
-    if (__ballot(roll && !slow) != 0ull) commit_segment_sweep<T, M, true, TC>(p, Xt, Ut, Kp, kp, SCt, alpha, xs, t0, t1, roll && !slow, seg == 0);
-    if (__ballot(slow) != 0ull) commit_segment_sweep<T, M, false, TC>(p, Xt, Ut, Kp, kp, SCt, alpha, xs, t0, t1, slow, seg == 0);
+    if (__ballot(roll && !slow) != 0ull) commit_segment_sweep<T, M, true, TC, RING>(p, Xt, Ut, Kp, kp, SCt, alpha, xs, t0, t1, roll && !slow, seg == 0);
+    if (__ballot(slow) != 0ull) commit_segment_sweep<T, M, false, TC, RING>(p, Xt, Ut, Kp, kp, SCt, alpha, xs, t0, t1, slow, seg == 0);
+}
+
+template <typename T, class M, bool TC>
+__global__ __launch_bounds__(64) void commit_segments_kernel(Params<T, M::NX, M::NU> p, int it, int nseg) {
+    commit_segments_body<T, M, TC>(p, it, nseg, (int)(blockIdx.x / nseg) * 64 + (int)threadIdx.x, (int)(blockIdx.x % nseg));
+}
+
+// ---------------------------------------------------------------- whole solve in one launch
+// The loop of ilqr.py:107-114 for the 256 / L problems of a workgroup, which never have to wait
+// for any other problem: backward pass (one lane per problem, first wave), line search (L lanes per
+// problem, A step sizes per lane, all four waves; keeps the candidates' checkpoints) and
+// time-parallel commit (one lane per problem and segment), separated by workgroup barriers instead
+// of kernel boundaries.  The phases are the device functions the per-phase kernels are made of and
+// exchange their data through the same arrays, so the results are the same bits.  With a launch per
+// phase a small batch is bound by the serial sweep of each phase while most of the chip idles
+// (the backward pass of 8192 problems occupies 128 of 1024 SIMDs); here the workgroups drift apart
+// and the latency-bound sweeps of some overlap the arithmetic of the line search of others, and a
+// workgroup whose problems have all converged leaves.
+// `may_reroll`: from the second iteration on the previous states may be rolled out again instead of
+// read (every problem still iterating has had a step committed by then).
+template <typename T, class M, bool DIAG, int CONSTR, int L, int A, int PFB>
+__global__ __launch_bounds__(256, 2) void solve_owned_kernel(Params<T, M::NX, M::NU> p, int max_iter, int nseg, int may_reroll) {
+    constexpr int G = 256 / L;
+    constexpr bool HAS_TRIG = trig_pairs<M>::value == 1;
+    constexpr bool BARRIER = (CONSTR & 2) != 0;
+    // the line search reads cached sine/cosine pairs only with two or more step sizes per lane (see eval_first)
+    constexpr bool EVAL_TC = HAS_TRIG && A >= 2;
+    __shared__ int live;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g0 = blockIdx.x * G;
+    for (int it = 0; it < max_iter; ++it) {
+        if (tid == 0) live = 0;
+        __syncthreads();
+        if (tid < G && g0 + tid < p.B && p.converged[g0 + tid] == 0) live = 1;
+        __syncthreads();
+        if (live == 0) break;
+        const bool again = it > 0 && may_reroll != 0;
+        const bool tc = HAS_TRIG && again && p.SC != nullptr;
+        // (the indices every phase derives its addresses from pass through an opaque statement, so that
+        // the compiler computes the addresses inside the phase instead of keeping the pointers of all
+        // three phases in registers across the whole loop)
+        int gb = g0 + tid, wv = blockIdx.x * 4 + w, ln = lane, tq = tid;
+        asm volatile("" : "+v"(gb), "+v"(wv), "+v"(ln), "+v"(tq));
+        if (tid < G) {
+            if constexpr (HAS_TRIG) {
+                if (tc)
+                    backward_body<T, M, DIAG, CONSTR, PFB, true>(p, gb);
+                else
+                    backward_body<T, M, DIAG, CONSTR, PFB, false>(p, gb);
+            } else {
+                backward_body<T, M, DIAG, CONSTR, PFB, false>(p, gb);
+            }
+        }
+        __syncthreads(); // gains
+                if (again) {
+            if constexpr (EVAL_TC) {
+                if (tc)
+                    evaluate_body<T, M, DIAG, BARRIER, L, A, true, true, true>(p, p.n_alphas, wv, ln);
+                else
+                    evaluate_body<T, M, DIAG, BARRIER, L, A, true, false, true>(p, p.n_alphas, wv, ln);
+            } else {
+                evaluate_body<T, M, DIAG, BARRIER, L, A, true, false, true>(p, p.n_alphas, wv, ln);
+            }
+        } else {
+            evaluate_body<T, M, DIAG, BARRIER, L, A, false, false, true>(p, p.n_alphas, wv, ln);
+        }
+        __syncthreads(); // accepted step sizes, trial costs, checkpoints
+        for (int q = tq; q < G * nseg; q += 256) {
+            if (HAS_TRIG && p.SC != nullptr)
+                commit_segments_body<T, M, HAS_TRIG, 2>(p, it, nseg, g0 + q % G, q / G);
+            else
+                commit_segments_body<T, M, false, 2>(p, it, nseg, g0 + q % G, q / G);
+        }
+        __syncthreads(); // trajectory, costs, flags
+    }
 }
 
 // ---------------------------------------------------------------- active-set compaction

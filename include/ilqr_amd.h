@@ -110,7 +110,13 @@ typedef struct ilqr_desc {
                                   (same bits; the sequential commit leaves a small batch's chip idle for N-1 dependent
                                   steps); 0 = auto (on up to 8192 problems); < 0: off.  Needs a single-stage line
                                   search with 4 or more lanes per problem, n <= 8, no compaction, one stream. */
-    int32_t reserved3;
+    int32_t fused_solve;       /* > 0: ilqr_solve runs all iterations in ONE launch in which a workgroup owns
+                                  256 / lanes_per_problem problems from the first backward pass to the last commit
+                                  (same bits as the launch-per-phase path; the latency-bound sweeps of some
+                                  workgroups overlap the line searches of others, and a workgroup whose problems
+                                  have all converged leaves); 0 = auto (on for small batches); < 0: off.  Needs what
+                                  segment_commit needs, and unconstrained problems; forces segment_commit on when
+                                  asked for explicitly.  The phase calls (ilqr_backward, ...) are not affected. */
     double dt;               /* system.dt (systems.py:30); the solver's own dt argument is unused (ilqr.py:20) */
     double lm_parameter;     /* ilqr.py:30, added to Vxx (ilqr.py:95) */
     double alpha_floor;      /* 1e-4 (ilqr.py:71) or alpha_terminal (cilqr.py:41) */

@@ -1166,3 +1166,79 @@ def test_full_size_ltv_batch(ilqr_cls, oracle, dtype):
     else:   # fp32 mode has its own bounds
         assert abs(hc[1, 0] - g["hist_cost"][0]) <= 1e-4 * g["hist_cost"][0]
         assert abs(J[1] - float(g["min_cost"])) <= 2e-3 * float(g["min_cost"])
+
+
+def test_single_launch_solve_does_not_change_a_bit(ilqr_cls, oracle):
+    """ilqr_solve with `fused_solve` runs every iteration of a workgroup's problems inside ONE launch
+    (backward pass, line search and time-parallel commit separated by workgroup barriers).  The
+    phases are the same device code as the launch-per-phase path, so every output must equal it bit
+    for bit: the three mappings it is built for, horizons shorter than one segment and not a
+    multiple of it, ragged batches (the last workgroup holds fewer problems than it owns), a
+    heading outside the fast sine/cosine range, an indefinite Quu, with and without the
+    sine/cosine cache, fp32, a second (continuing) call, and a run-time compiled model."""
+    from ilqr_amd import problems
+    keys = ("states", "inputs", "min_cost", "iterations", "converge", "status")
+    for N, B in ((110, 150), (9, 70), (33, 5), (66, 131), (3, 9), (200, 64)):
+        p = problems.car_batch(B, N)
+        if B > 7:
+            p["init_states"][7, :, 3] += 3.0e6
+            p["target_states"][7, :, 3] += 3.0e6
+        ref = _solve_batch(ilqr_cls, p, segment_commit=-1, trig_cache=-1, fused_solve=-1)
+        Kr, kr = ref.K.copy(), ref.k.copy()
+        for kw in (dict(lanes_per_problem=16, alphas_per_lane=1), dict(lanes_per_problem=8, alphas_per_lane=2),
+                   dict(lanes_per_problem=4, alphas_per_lane=4), dict(lanes_per_problem=8, alphas_per_lane=2, trig_cache=-1),
+                   dict(lanes_per_problem=4, alphas_per_lane=4, recompute_states=-1)):
+            o = _solve_batch(ilqr_cls, p, fused_solve=1, **kw)
+            for key in keys:
+                assert np.array_equal(getattr(o, key), getattr(ref, key), equal_nan=True), (N, B, kw, key)
+            assert np.array_equal(o.alpha_history, ref.alpha_history)
+            assert np.array_equal(o.cost_history, ref.cost_history, equal_nan=True)
+            assert np.array_equal(o.K, Kr) and np.array_equal(o.k, kr), (N, B, kw)
+    # against the oracle directly, and a second call that continues (ilqr.py:107-111)
+    p = problems.car_batch(70, 90)
+    car = demo_car_system()
+    o = ilqr_cls(car, p["target_states"], car.dt, history=True, fused_solve=1)
+    r = ilqr_cls(car, p["target_states"], car.dt, history=True, fused_solve=-1)
+    for s in (o, r):
+        s.inputs, s.states, s.maxIter = p["init_inputs"].copy(), p["init_states"].copy(), 6
+        s()
+    d = oracle.make_desc(car, 90, max_iter=6)
+    ro = oracle.solve_batch(d, p["target_states"], p["init_states"].copy(), p["init_inputs"].copy())
+    assert (np.abs(o.cost_history[:, :6] - ro["hist_cost"][:, :6]) / np.abs(ro["hist_cost"][:, :6])).max() <= 1e-9
+    for s in (o, r):
+        s()
+    for key in keys:
+        assert np.array_equal(getattr(o, key), getattr(r, key), equal_nan=True), key
+    # indefinite Quu (negative input weight): status bits and gains as the phase path's
+    pq = problems.car_batch(40, 50)
+    outs = []
+    for fs in (-1, 1):
+        c2 = demo_car_system()
+        c2.set_cost(np.diag([50.0, 50.0, 1000.0, 0.0]), np.diag([-50.0, 1000.0]))   # indefinite R
+        s = ilqr_cls(c2, pq["target_states"], c2.dt, history=True, fused_solve=fs, lanes_per_problem=16, alphas_per_lane=1)
+        s.inputs, s.states, s.maxIter = pq["init_inputs"].copy(), pq["init_states"].copy(), 4
+        s()
+        outs.append(s)
+    assert (outs[0].status != 0).any()
+    for key in keys:
+        assert np.array_equal(getattr(outs[0], key), getattr(outs[1], key), equal_nan=True), key
+    assert np.array_equal(outs[0].K, outs[1].K, equal_nan=True)
+    # fp32
+    p = problems.car_batch(90, 70)
+    a = _solve_batch(ilqr_cls, p, fused_solve=-1, dtype=np.float32)
+    b = _solve_batch(ilqr_cls, p, fused_solve=1, dtype=np.float32)
+    assert np.array_equal(a.states, b.states) and np.array_equal(a.inputs, b.inputs) and np.array_equal(a.min_cost, b.min_cost)
+    # a run-time compiled model
+    from ilqr_amd.user_models import KinematicBicycle
+    q = problems.bicycle_batch(33, 60)
+    outs = []
+    for fs in (-1, 1):
+        s = KinematicBicycle()
+        s.set_cost(problems.BICYCLE_Q.copy(), problems.BICYCLE_R.copy())
+        s.set_control_limit(*problems.BICYCLE_LIMITS)
+        o = ilqr_cls(s, q["target_states"], s.dt, history=True, fused_solve=fs)
+        o.inputs, o.states = q["init_inputs"].copy(), q["init_states"].copy()
+        o()
+        outs.append(o)
+    for key in ("states", "inputs", "min_cost", "iterations", "converge"):
+        assert np.array_equal(getattr(outs[0], key), getattr(outs[1], key)), key

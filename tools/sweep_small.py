@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--mappings", default="0x0,16x1,8x2,4x4,8x1,4x2")
     ap.add_argument("--streams", default="1,2,4")
     ap.add_argument("--recompute", default="0,-1")
+    ap.add_argument("--fused", default="-1", help="fused_solve values, e.g. -1,1")
     a = ap.parse_args()
     import torch
     car = systems.Car()
@@ -35,10 +36,10 @@ def main():
     car.set_control_limit(*problems.CAR_LIMITS)
     for B in (int(v) for v in a.batches.split(",")):
         p = problems.car_batch(B, 200)
-        for mp, ns, rc in itertools.product(a.mappings.split(","), a.streams.split(","), a.recompute.split(",")):
+        for mp, ns, rc, fs in itertools.product(a.mappings.split(","), a.streams.split(","), a.recompute.split(","), a.fused.split(",")):
             L, A = (int(v) for v in mp.split("x"))
             opt = iterative_LQR(car, p["target_states"], 0.2, lanes_per_problem=L, alphas_per_lane=A, n_streams=int(ns),
-                                recompute_states=int(rc), repack_every=-1)
+                                recompute_states=int(rc), repack_every=-1, fused_solve=int(fs))
             opt.inputs, opt.states = p["init_inputs"], p["init_states"]
             dev = opt.upload()
             X0, U0 = dev.X.clone(), dev.U.clone()
@@ -50,7 +51,7 @@ def main():
                 opt.solve_device()
                 torch.cuda.synchronize()
                 times.append(time.perf_counter() - t0)
-            print(json.dumps({"B": B, "mapping": dev.forward_mapping(), "streams": int(ns), "recompute_states": int(rc),
+            print(json.dumps({"B": B, "mapping": dev.forward_mapping(), "streams": int(ns), "recompute_states": int(rc), "fused": int(fs),
                               "ms_per_solve": round(1e3 * float(np.median(times[1:])), 3)}), flush=True)
             del opt, dev, X0, U0
     torch.cuda.empty_cache()
