@@ -35,18 +35,20 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
 
-def algorithmic_bytes(N, n, m, w=8):
+def algorithmic_bytes(N, n, m, w=8, sparse=False):
     """Bytes each kernel must move per problem it works on (w bytes per value), the least the
     phase decomposition allows: backward reads X, U, Xref and writes K, k; the line search reads
     K, k, U, Xref and x0 once for all step sizes (the previous states follow from x0 and U);
-    the commit reads K, k, U, x0 and writes the accepted X, U."""
+    the commit reads K, k, U, x0 and writes the accepted X, U.  With sparse states only every 8th
+    state row passes between the commit and the backward pass."""
     T = N - 1
     gains = T * m * n + T * m
+    xrows = (T + 7) // 8 if sparse else N      # state rows written by the commit, read by the backward pass
     return {
-        "backward": w * (2 * N * n + T * m + gains),
+        "backward": w * (xrows * n + N * n + T * m + gains),
         "evaluate_first": w * (gains + T * m + N * n + n),
         "evaluate_rest": w * (gains + T * m + N * n + n),
-        "commit": w * (gains + T * m + n + N * n + T * m),
+        "commit": w * (gains + T * m + n + xrows * n + T * m),
     }
 
 
@@ -66,6 +68,8 @@ def main():
     ap.add_argument("--no-repack", action="store_true")
     ap.add_argument("--segment-commit", type=int, default=0, help="time-parallel commit: 0 = the library's choice, -1 off, 1 on")
     ap.add_argument("--trig-cache", type=int, default=0, help="sine/cosine cache: 0 = the library's choice, -1 off, 1 on")
+    ap.add_argument("--sparse-states", type=int, default=0,
+                    help="commits keep every 8th state row only: 0 = what ilqr_solve picks (on from 32768 problems per GPU), -1 off, 1 on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=65536, help="upper bound on problems in the CPU baseline sample")
     args = ap.parse_args()
@@ -98,9 +102,11 @@ def main():
     np_dtype = np.float64 if args.dtype == "f64" else np.float32
     repack_every = 0 if args.no_repack else (args.repack_every if args.repack_every is not None else (8 if B >= 32768 else 0))
     # the handle is created with the same period, so that it holds the workspace ilqr_repack needs
+    # sparse states between the phase calls as inside ilqr_solve (recompute_states: 1 = never, 2 = always)
+    sparse = args.sparse_states > 0 or (args.sparse_states == 0 and B >= 32768)
     opt = iterative_LQR(car, p["target_states"], car.dt, history=True, dtype=np_dtype,
                         repack_every=repack_every if repack_every > 0 else -1, segment_commit=args.segment_commit,
-                        trig_cache=args.trig_cache, **kw)
+                        trig_cache=args.trig_cache, recompute_states=2 if sparse else 1, **kw)
     opt.inputs, opt.states = p["init_inputs"], p["init_states"]
     dev = opt.upload()
     X0, U0 = dev.X.clone(), dev.U.clone()
@@ -142,6 +148,7 @@ def main():
                 dev.forward(it)
         if repack_every > 0:
             dev.unpack()
+        dev.fill_states()     # every state row again (a no-op without sparse states, or after the unpack)
 
     for _ in range(args.warmup):
         solve_step()
@@ -181,7 +188,10 @@ def main():
     for e in events:
         for i, k in enumerate(names):
             kt[k].append(e[i].elapsed_time(e[i + 1]))
-    ab = algorithmic_bytes(N, 4, 2, 8 if args.dtype == "f64" else 4)
+    ab = algorithmic_bytes(N, 4, 2, 8 if args.dtype == "f64" else 4, sparse)
+    ab0 = algorithmic_bytes(N, 4, 2, 8 if args.dtype == "f64" else 4, False)
+    # bytes per problem in iteration `it`: the first backward pass and the first commit move every state row
+    ab_it = {k: np.array([ab0[k] if it == 0 else ab[k] for it in range(max_iter)], dtype=np.float64) for k in ab}
     L_, A_ = dev.forward_mapping()
     n_alphas = dev.num_alphas()
     # problems the second line-search stage works on: no improvement among the first L*A step sizes
@@ -193,7 +203,7 @@ def main():
         ms = np.array(ms).reshape(args.steps, max_iter)
         live = units[name] > 0
         total_ms = ms[:, live].sum()
-        total_bytes = float(args.steps) * float((units[name][live] * ab[name]).sum())
+        total_bytes = float(args.steps) * float((units[name][live] * ab_it[name][live]).sum())
         kernels[name] = {
             "launches": int(live.sum()) * args.steps,
             "avg_ms": float(total_ms / max(1, live.sum() * args.steps)),
@@ -233,7 +243,8 @@ def main():
                                    + ", maxIter=30, 15 parallel step sizes",
                        "batch_per_gpu": B, "batch_total": B_total, "horizon": N,
                        "forward_mapping": f"L={L_},A={A_} ({'two-stage' if L_ * A_ < n_alphas else 'one stage'})",
-                       "active_set_compaction_every": repack_every},
+                       "active_set_compaction_every": repack_every,
+                       "sparse_states": bool(sparse)},
             "mean_iterations_per_solve": float(iter_sum[0].item()) / B_total,
             "converged_fraction": float(iter_sum[1].item()) / B_total,
             "executed_iterations_per_step": float(iter_sum[0].item()),
@@ -245,8 +256,8 @@ def main():
                 "bytes_per_problem_per_launch": ab[dominant],
             },
             "kernels": kernels,
-            "solve_achieved_GBs": float(args.steps * (active * (ab["backward"] + ab["evaluate_first"]) + listed * ab["evaluate_rest"]
-                                                      + accepted * ab["commit"]).sum()
+            "solve_achieved_GBs": float(args.steps * (active * (ab_it["backward"] + ab_it["evaluate_first"]) + listed * ab_it["evaluate_rest"]
+                                                      + accepted * ab_it["commit"]).sum()
                                         / elapsed / 1e9) * world,   # rank 0's shard x ranks (shards are equal up to one tile)
             "ilqr_solve_ms": ilqr_solve_ms,     # one ilqr_solve() call on the same inputs (host clock, rank 0, untimed region)
         }

@@ -80,6 +80,7 @@ _SIGNATURES = {
     "ilqr_solve": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "ilqr_solve_static": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "ilqr_rollout": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ilqr_states": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ilqr_active_count": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "ilqr_to_tiled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ilqr_from_tiled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

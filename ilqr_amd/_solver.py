@@ -253,6 +253,7 @@ class DeviceProblem:
     # -- data movement ------------------------------------------------------
     def upload(self, target_states, states, inputs, converged=None, centers=None, radius=None):
         N, n, m = self.N, self.n, self.m
+        self.fill_states()   # (the library must not hold sparse states of its own when X is rewritten)
         self._upload(target_states, self.Xref, N * n)
         self._upload(states, self.X, N * n)
         self._upload(inputs, self.U, (N - 1) * m)
@@ -267,6 +268,7 @@ class DeviceProblem:
             self._upload(radius, self.radius, N)
 
     def download_states(self):
+        self.fill_states()   # (a no-op unless sparse commits have run between phase calls)
         return self._download(self.X, self.N * self.n, (self.B, self.N, self.n))
 
     def download_inputs(self):
@@ -293,6 +295,11 @@ class DeviceProblem:
 
     def repack(self):
         _lib.check(self.lib.ilqr_repack(self.handle, self.stream()), "ilqr_repack")
+
+    def fill_states(self):
+        """Bring X up to date (handles created with ``recompute_states=2`` keep only every 8th state
+        row between the phase calls)."""
+        _lib.check(self.lib.ilqr_states(self.handle, self.stream()), "ilqr_states")
 
     def unpack(self):
         _lib.check(self.lib.ilqr_unpack(self.handle, self.stream()), "ilqr_unpack")

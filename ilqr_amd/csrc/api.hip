@@ -22,6 +22,7 @@ struct PartState {
     HostCtx ctx;      // launch context of this part (tile range [first, first + count))
     int index = 0;    // part number
     bool packed = false;
+    bool stale = false; // a sparse commit has run since X was last filled in (HostCtx::lazy)
     int parity = 0;   // working set in use once packed
 };
 
@@ -35,6 +36,8 @@ struct ilqr_handle {
     bool trig = false;      // sine/cosine cache in `work` (HostCtx::trig)
     bool seg = false;       // candidate checkpoints in `work`, time-parallel commit (HostCtx::seg)
     bool fused = false;     // ilqr_solve runs its iterations in one launch (solve_owned_kernel)
+    bool lazy_solve = false; // sparse states inside ilqr_solve (HostCtx::lazy)
+    bool lazy_calls = false; // ... and between the phase calls: the caller asks for X with ilqr_states
     // the phase calls (ilqr_backward ...) and the single-stream ilqr_solve work on the whole batch as
     // one part whose compaction state lives here, between calls
     PartState whole;
@@ -239,12 +242,22 @@ static hipError_t repack_launch(ilqr_handle *h, PartState &ps, int mode, hipStre
     return hipSuccess;
 }
 
+// X of this part in full again, if sparse commits have run since it last was
+static int fill_states(ilqr_handle *h, PartState &ps, hipStream_t s) {
+    if (!ps.stale) return ILQR_OK;
+    ps.stale = false;
+    return h->ops->states ? hip_rc(h->ops->states(ps.ctx, 0, s)) : ILQR_ERR_UNSUPPORTED;
+}
+
 static int repack(ilqr_handle *h, PartState &ps, int mode, hipStream_t s) {
+    // the rows are moved as they are: whoever retires or carries a trajectory needs all of it
+    if (int rc = fill_states(h, ps, s); rc != ILQR_OK) return rc;
     return hip_rc(h->ctx.d.dtype == ILQR_F64 ? repack_launch<double>(h, ps, mode, s) : repack_launch<float>(h, ps, mode, s));
 }
 
 // End of a solve whose part was compacted: everything goes back to the caller's buffers.
 static int unpack(ilqr_handle *h, PartState &ps, hipStream_t s) {
+    if (int rc0 = fill_states(h, ps, s); rc0 != ILQR_OK) return rc0;
     if (!ps.packed) return ILQR_OK; // everything is in the caller's buffers already
     int rc = repack(h, ps, REPACK_RETIRE_ALL, s);
     if (rc != ILQR_OK) return rc;
@@ -380,6 +393,13 @@ int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
     // (unconstrained at 16384: 14.6 against 14.5 ms, no gain; the constrained solver's long tail of
     // iterations with few active problems gains at 16384 too: 58.0 -> 55.2 ms)
     h->ctx.seg = h->seg;
+    // Sparse states (recompute_states: 0 = auto, 1 = never, 2 = everywhere).  They save traffic, which
+    // is what bounds large batches; small ones are bound by the instruction stream of a sweep.
+    {
+        const bool ok = ops->states != nullptr && d.n <= 8 && (d.constraint_mode & 3) == 0 && !h->trig && !h->seg && d.overlap_stages <= 0;
+        h->lazy_calls = ok && d.recompute_states >= 2;
+        h->lazy_solve = ok && (d.recompute_states >= 2 || (d.recompute_states == 0 && d.B >= 32768));
+    }
     // off unless asked for: beside the bandwidth-bound commit the latency-bound second stage runs
     // 2.5x slower and slows the commit down (measured: 34.8 -> 42.0 ms per solve at B = 65536)
     h->overlap = d.overlap_stages > 0 && h->n_parts == 1;
@@ -469,6 +489,7 @@ static HostCtx &phase_ctx(ilqr_handle *h) {
     h->whole.ctx.select_converged = false;
     h->whole.ctx.trig = h->trig;
     h->whole.ctx.seg = h->seg;
+    h->whole.ctx.lazy = h->lazy_calls;
     h->whole.ctx.eval_stages = 3;
     h->whole.ctx.side = h->ctx.side;
     h->whole.ctx.ev_fork = h->ctx.ev_fork;
@@ -479,9 +500,28 @@ static HostCtx &phase_ctx(ilqr_handle *h) {
 #define REQUIRE_UNPACKED(h) \
     if ((h)->whole.packed) return ILQR_ERR_INVALID; /* ilqr_unpack first: the caller's buffers are stale */
 
+// every call that reads or moves X outside the iteration first has it filled in (sparse states)
+#define FILL_STATES(h, stream)                                                       \
+    if ((h)->whole.stale) {                                                          \
+        phase_ctx(h);                                                                \
+        if (int rcf = fill_states((h), (h)->whole, (hipStream_t)(stream)); rcf != ILQR_OK) return rcf; \
+    }
+
+// Calls that start from a trajectory the caller may have written: X filled in by the library now would
+// overwrite it, X left sparse would be read as it is; the caller says which by calling ilqr_states first.
+#define REQUIRE_STATES(h) \
+    if ((h)->whole.stale) return ILQR_ERR_INVALID; /* ilqr_states first: X holds only every 8th state row */
+
+int ilqr_states(ilqr_handle *h, void *stream) {
+    REQUIRE_BOUND(h); // (sparse states between phase calls imply a bound workspace: those calls need one)
+    FILL_STATES(h, stream);
+    return ILQR_OK;
+}
+
 int ilqr_initial_cost(ilqr_handle *h, void *stream) {
     REQUIRE_WORK(h);
     REQUIRE_UNPACKED(h);
+    REQUIRE_STATES(h);
     h->ctx.reroll = false; // the caller (re)wrote X and U: X need not be the rollout of U
     return hip_rc(h->ops->cost(h->ctx, 0, (hipStream_t)stream));
 }
@@ -511,6 +551,7 @@ int ilqr_forward_commit(ilqr_handle *h, int32_t iteration, void *stream) {
     if (iteration < 0) return ILQR_ERR_INVALID;
     if (hipError_t e = ensure_side(h); e != hipSuccess) return hip_rc(e);
     const int rc = hip_rc(h->ops->commit(phase_ctx(h), iteration, (hipStream_t)stream));
+    if (h->lazy_calls && h->ctx.reroll) h->whole.stale = true; // (a sparse commit, if the launch table has one for this handle)
     // every problem that is still active afterwards has had a step committed by this library
     if (rc == ILQR_OK && h->ctx.d.recompute_states >= 0) h->ctx.reroll = true;
     return rc;
@@ -576,6 +617,7 @@ static int solve_impl(ilqr_handle *h, int32_t max_iter, void *work, bool compact
         part[s].ctx.b.work = work;
         part[s].ctx.trig = extras && h->trig;
         part[s].ctx.seg = extras && h->seg;
+        part[s].ctx.lazy = h->lazy_solve;
         part[s].index = s;
         const int t0 = (int)((long)tiles * s / np), t1 = (int)((long)tiles * (s + 1) / np);
         part[s].ctx.first = t0 * TILE;
@@ -614,6 +656,7 @@ static int solve_impl(ilqr_handle *h, int32_t max_iter, void *work, bool compact
                 rc = hip_rc(h->ops->evaluate(part[s].ctx, 0, st[s]));
             }
             if (rc == ILQR_OK) rc = hip_rc(h->ops->commit(part[s].ctx, it, st[s]));
+            if (part[s].ctx.lazy && part[s].ctx.reroll) part[s].stale = true;
         }
     for (int s = 0; s < np; ++s) {
         if (rc == ILQR_OK) rc = unpack(h, part[s], st[s]); // retire what is still in a working set
@@ -631,6 +674,7 @@ int ilqr_solve(ilqr_handle *h, int32_t max_iter, void *stream) {
     if (max_iter < 0) return ILQR_ERR_INVALID;
     REQUIRE_UNPACKED(h);
     if (!h->ctx.b.work) return ILQR_ERR_NOT_BOUND;
+    REQUIRE_STATES(h);
     return solve_impl(h, max_iter, h->ctx.b.work, true, true, stream);
 }
 
@@ -638,6 +682,7 @@ int ilqr_solve_static(ilqr_handle *h, int32_t max_iter, void *stream) {
     REQUIRE_BOUND(h);
     if (max_iter < 0) return ILQR_ERR_INVALID;
     REQUIRE_UNPACKED(h);
+    REQUIRE_STATES(h);
     // streams and events of its own would have to be created: not in a call that must not allocate
     if (h->n_parts > 1 || h->overlap) return ILQR_ERR_UNSUPPORTED;
     const size_t need = work_layout(h->ctx.d, false).total;
@@ -668,6 +713,7 @@ int ilqr_rollout(ilqr_handle *h, void *stream) {
     REQUIRE_BOUND(h);
     REQUIRE_UNPACKED(h);
     h->ctx.reroll = false; // X was rewritten by something other than a commit
+    h->whole.stale = false; // (every row of it)
     return hip_rc(h->ops->rollout(h->ctx, 0, (hipStream_t)stream));
 }
 
@@ -700,6 +746,7 @@ int ilqr_shift(ilqr_handle *h, int32_t shift, const void *x0, void *stream) {
     const ilqr_desc &d = h->ctx.d;
     if (shift < 0 || shift >= d.N) return ILQR_ERR_INVALID;
     REQUIRE_UNPACKED(h);
+    FILL_STATES(h, stream);
     const ilqr_buffers &b = h->ctx.b;
     const dim3 grid((d.B + TILE - 1) / TILE), block(64);
     hipStream_t s = (hipStream_t)stream;

@@ -31,6 +31,10 @@ struct HostCtx {
     // time-parallel commit: the (single-stage) line search keeps candidate checkpoints in `work`
     // (Params::CK) and the commit rolls all segments out at once (commit_segments_kernel)
     bool seg = false;
+    // sparse states (Params::lazy): commits mark the problems they roll out with the fast sine/cosine,
+    // and once `reroll` holds they store only every XCK-th state row and the backward pass regenerates
+    // the rest; ModelOps::states fills X in again
+    bool lazy = false;
     int eval_stages = 3;           // line search: bit 0 = stage one, bit 1 = stage two (see evaluate_kernel)
     // stage two fused with the commit of its problems, beside the commit of the others: the stream
     // and events it runs on (null: stage two runs before the commit, on the caller's stream)
@@ -116,6 +120,8 @@ struct ModelOps {
     // `it` iterations of backward pass + line search + commit in ONE launch (solve_owned_kernel), for a context
     // that runs the time-parallel commit (HostCtx::seg); hipErrorNotSupported if the combination is not built
     launch_fn solve;
+    // fills in the state rows sparse commits left out (states_kernel); null if the model has no sparse variant
+    launch_fn states;
 };
 
 // What a separately compiled model library (ilqr_load_model) hands to this one.  `abi` must equal
@@ -130,7 +136,7 @@ struct PluginInfo {
     const ModelOps *(*ops)(int dtype, bool diag);
     const SqpOps *(*sqp)(int dtype); // sequential-QP kernels for this model, or a function returning null
 };
-constexpr int32_t PLUGIN_ABI_VERSION = 5;
+constexpr int32_t PLUGIN_ABI_VERSION = 6;
 static inline int32_t plugin_abi() {
     return (int32_t)(PLUGIN_ABI_VERSION * 1000003u + sizeof(HostCtx) * 31u + sizeof(ilqr_desc) * 7u + sizeof(ilqr_buffers));
 }
@@ -201,6 +207,7 @@ template <typename T, int NX, int NU> static Params<T, NX, NU> make_params(const
     p.N = d.N;
     p.n_alphas = c.n_alphas;
     p.select_converged = c.select_converged ? 1 : 0;
+    p.lazy = c.lazy ? 1 : 0;
     // (indexed like the other per-problem arrays: by global problem index through the slot map, by
     // the index within the part otherwise)
     p.carried = c.select_converged ? flat((const int32_t *)((char *)b.work + work_layout(d, true).carried)) : nullptr;
@@ -241,6 +248,9 @@ template <typename T, int NX, int NU> static Params<T, NX, NU> make_params(const
 #ifndef ILQR_PF_COMMIT
 #define ILQR_PF_COMMIT 2
 #endif
+#ifndef ILQR_PF_COMMIT_SPARSE
+#define ILQR_PF_COMMIT_SPARSE 4
+#endif
 constexpr int PF_BACKWARD = ILQR_PF_BACKWARD;
 constexpr int PF_COMMIT = ILQR_PF_COMMIT;
 // a row of the 12-state model is 56 values: a second row in flight spills (1148 bytes of scratch per lane)
@@ -274,8 +284,21 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
         return M::NX <= 8 && c.seg && c.L >= 4 && c.L * c.A >= c.n_alphas && c.n_alphas <= CK_CANDIDATES && c.ws.slot2orig == nullptr &&
                c.side == nullptr;
     }
+    // sparse states: the lane-per-problem kernels of the small models, unconstrained, without the
+    // sine/cosine cache, the candidate checkpoints and a second stage that commits on its own
+    static constexpr bool LAZY_BUILT = M::NX <= 8;
+    static bool use_lazy(const HostCtx &c) {
+        return LAZY_BUILT && c.lazy && (c.d.constraint_mode & 3) == 0 && !c.trig && !c.seg && c.side == nullptr && !c.select_converged &&
+               c.d.recompute_states >= 0;
+    }
     template <int CONSTR> static hipError_t backward_c(const HostCtx &c, hipStream_t s) {
         auto p = make_params<T, NX, NU>(c);
+        if constexpr (LAZY_BUILT && CONSTR == 0) {
+            if (use_lazy(c) && c.reroll) {
+                hipLaunchKernelGGL((backward_gen_kernel<T, M, DIAG, 0, PF_BACKWARD>), dim3((c.count + 63) / 64), dim3(64), 0, s, p);
+                return hipGetLastError();
+            }
+        }
         if constexpr (HAS_TRIG) {
             if (use_trig(c)) {
                 hipLaunchKernelGGL((backward_kernel<T, M, DIAG, CONSTR, PF_BACKWARD, true>), dim3((c.count + 63) / 64), dim3(64), 0, s, p);
@@ -448,6 +471,7 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
     }
     template <bool REROLL> static hipError_t commit_r(const HostCtx &c, int it, hipStream_t s) {
         auto p = make_params<T, NX, NU>(c);
+        if (!use_lazy(c)) p.lazy = 0; // (no marks without the kernels that honour them)
         if constexpr (std::is_same<M, LtvModelT<T, 12, 4>>::value && DIAG) {
             // 16 problems per wave on the matrix unit (kernels.hpp), whenever the line search was the
             // single-stage matrix-unit kernel
@@ -465,6 +489,13 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
                     hipLaunchKernelGGL((commit_segments_kernel<T, M, HAS_TRIG>), grid, dim3(64), 0, s, p, it, nseg);
                 else
                     hipLaunchKernelGGL((commit_segments_kernel<T, M, false>), grid, dim3(64), 0, s, p, it, nseg);
+                return hipGetLastError();
+            }
+        }
+        if constexpr (LAZY_BUILT && REROLL) {
+            if (use_lazy(c)) {
+                // (four rows in flight: this variant reads five times what it writes, and only its own loads hide the latency)
+                hipLaunchKernelGGL((commit_kernel<T, M, ILQR_PF_COMMIT_SPARSE, true, false, true>), dim3((c.count + 63) / 64), dim3(64), 0, s, p, it);
                 return hipGetLastError();
             }
         }
@@ -549,8 +580,17 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
         }
         return hipErrorNotSupported;
     }
+    static hipError_t states(const HostCtx &c, int, hipStream_t s) {
+        if constexpr (LAZY_BUILT) {
+            auto p = make_params<T, NX, NU>(c);
+            hipLaunchKernelGGL((states_kernel<T, M>), dim3((c.count + 63) / 64), dim3(64), 0, s, p);
+            return hipGetLastError();
+        }
+        return hipErrorNotSupported;
+    }
     static const ModelOps *table() {
-        static const ModelOps ops = {&cost, &backward, &evaluate, &commit, &probe, &rollout, trig_pairs<M>::value, &solve};
+        static const ModelOps ops = {&cost, &backward, &evaluate, &commit, &probe, &rollout, trig_pairs<M>::value, &solve,
+                                     LAZY_BUILT ? &states : nullptr};
         return &ops;
     }
 };

@@ -112,6 +112,9 @@ constexpr int TILE = 64;
 #define ILQR_COMMIT_SEG 32
 #endif
 constexpr int COMMIT_SEG = ILQR_COMMIT_SEG;
+// Sparse states: a commit may keep only every XCK-th row of X (see Params::lazy)
+constexpr int XCK = 8;
+constexpr int SLOW_TRIG_REGEN = 8; // bit of Params::slow_trig: rows 0, XCK, 2 XCK .. of X and U regenerate the trajectory
 constexpr int CK_CANDIDATES = 16; // candidate slots per segment start
 template <typename T> __device__ __forceinline__ T *tile_ptr(T *base, int tile, int rows, int lane) {
     return base + (size_t)tile * (size_t)rows * TILE + lane;
@@ -164,6 +167,16 @@ template <typename T, int NX, int NU> struct Params {
     int32_t n_alphas;
     int32_t slots_lo, slots_hi; // evaluate_kernel runs only if slots_lo < number of slots <= slots_hi
     int32_t select_converged; // backward pass only: work on the converged problems instead of the active ones
+    // Sparse states (0 = off).  Between a commit and the next backward pass the states are only ever
+    // needed in reverse order, and every state is the model step of its predecessor under the stored
+    // input, by the very instruction sequence of the commit.  With `lazy` a commit that rolls a problem
+    // out with the fast sine/cosine marks it (SLOW_TRIG_REGEN in slow_trig) and, in its sparse variant,
+    // stores only the state rows 0, XCK, 2 XCK ..; the backward pass rolls each segment of XCK steps
+    // out again from its first row before it walks it backwards (the sine/cosine pair of that step is
+    // the one the Jacobians need, so the arithmetic is what it was), and states_kernel fills in the
+    // rows in between when somebody wants to read X.  Same bits, 5600 + 5600 of the 60 600 bytes the
+    // two passes move per Car problem (N = 200) less.
+    int32_t lazy;
     T dt, lm, lambda, mu, delta, vlo, vhi;
     T Q[NX * NX], R[NU * NU], Qf[NX * NX];
     T Q2[NX * NX], R2[NU * NU], Qf2[NX * NX];
@@ -774,7 +787,8 @@ template <typename T, int NX, int NU> struct StepRow { // the rows of one time s
 // stores from every lane, see below; the redo sweep must leave the gains of the other lanes alone)
 // TC: sine/cosine pairs are read from SCp (Params::SC) and `store` also guards the fast sweep (the
 // lanes of converged problems may hold no valid pairs, so they must not rewrite their gains).
-template <typename T, class M, bool DIAG, int CONSTR, int PF, bool FAST, bool TC = false, class P>
+// COND: also the fast sweep stores only for the lanes with `store`.
+template <typename T, class M, bool DIAG, int CONSTR, int PF, bool FAST, bool TC = false, bool COND = false, class P>
 __device__ __forceinline__ int backward_sweep(const P &p, const T *Xt, const T *Rt, const T *Ut, const T *Cp, const T *Dp,
                                               T *Kp, T *kp, bool &bad, bool store = true, const T *SCp = nullptr) {
     constexpr int NX = M::NX, NU = M::NU;
@@ -847,7 +861,7 @@ __device__ __forceinline__ int backward_sweep(const P &p, const T *Xt, const T *
             // changed, so they rewrite the same bits) and the padding lanes of the last tile: a
             // branch around the stores would make the number of outstanding memory operations
             // path-dependent and force full drains of the memory queue in the loop
-            if ((FAST && !TC) || store) {
+            if ((FAST && !TC && !COND) || store) {
 #pragma unroll
                 for (int i = 0; i < NU; ++i) {
                     kp[(t * NU + i) * TILE] = kt[i];
@@ -902,6 +916,211 @@ __device__ __forceinline__ void backward_body(const P &p, int b0) {
 template <typename T, class M, bool DIAG, int CONSTR, int PF, bool TC = false>
 __global__ __launch_bounds__(64) void backward_kernel(Params<T, M::NX, M::NU> p) {
     backward_body<T, M, DIAG, CONSTR, PF, TC>(p, blockIdx.x * 64 + threadIdx.x);
+}
+
+// The reverse sweep for a problem of whose states only the rows 0, XCK, 2 XCK .. are stored
+// (Params::lazy): the horizon in segments of XCK steps, last segment first; each is rolled out
+// forward from its stored first state under the stored inputs (the commit's instruction sequence, so
+// these are the states the commit had in registers), keeping the states and, for a model with a
+// shared sine/cosine pair, the pairs, and is then walked backwards by riccati_step.  The rows of the
+// segment after next are under way meanwhile.  PRED: only the lanes with `store` write their gains
+// (else every lane does, see backward_sweep).
+template <typename T, class M, bool DIAG, int CONSTR, bool FAST, bool PRED, class P>
+__device__ __forceinline__ int backward_sweep_gen(const P &p, const T *Xt, const T *Rt, const T *Ut, T *Kp, T *kp, bool &bad, bool store) {
+    constexpr int NX = M::NX, NU = M::NU, S = XCK;
+    constexpr bool SHARED = trig_pairs<M>::value == 1;
+    static_assert((CONSTR & 2) == 0, "the regenerating sweep is built without the barrier terms");
+    const int T1 = p.N - 1;
+    const int nseg = (T1 + S - 1) / S;
+    struct Head { // the rows of a segment: its first state, its inputs, its targets
+        T x0[NX], u[S][NU], xr[S][NX];
+    };
+    auto load_head = [&](int seg, Head &h) {
+        const int t0 = seg * S;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) h.x0[i] = Xt[(t0 * NX + i) * TILE];
+#pragma unroll
+        for (int q = 0; q < S; ++q) {
+            const int t = t0 + q < T1 ? t0 + q : T1 - 1; // (past the horizon the last row again: no branch around a load)
+#pragma unroll
+            for (int i = 0; i < NU; ++i) h.u[q][i] = Ut[(t * NU + i) * TILE];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) h.xr[q][i] = Rt[(t * NX + i) * TILE];
+        }
+    };
+    T Vx[NX], Vxx[NX][NX];
+    Head cur, nxt;
+    load_head(nseg - 1, cur);
+    int status = 0;
+    // one segment; GUARD: it may be shorter than S (only the last one is), the steps past its end are skipped
+    auto segment = [&](int seg, auto guard_tag) {
+        constexpr bool GUARD = decltype(guard_tag)::value;
+        const int t0 = seg * S;
+        const int len = GUARD ? (T1 - t0 < S ? T1 - t0 : S) : S;
+        if (seg > 0) load_head(seg - 1, nxt); // a whole segment ahead: a segment takes a few microseconds, a loaded row about as long
+        T x[S + 1][NX], ss[S], cc[S];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[0][i] = cur.x0[i];
+#pragma unroll
+        for (int q = 0; q < S; ++q) { // (past the end of a short segment: harmless arithmetic on the last row)
+            ss[q] = cc[q] = T(0);
+            // always the fast routine: the mark says the commit used it (all its angles were in range).
+            // The fallback sweep (!FAST) regenerates the same states and lets riccati_step evaluate the
+            // Jacobians' pair with the library routine, as the reading sweep does.
+            bool b2 = false;
+            model_step<true, false, M>(p, t0 + q, x[q], cur.u[q], x[q + 1], ss[q], cc[q], b2);
+            if (FAST && (!GUARD || q < len)) bad = bad || b2;
+        }
+        if (GUARD) {
+            // terminal condition (ilqr.py:79-82) at the state after the last step
+            T xT[NX], e[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xT[i] = x[S][i];
+#pragma unroll
+            for (int q = S - 1; q >= 1; --q)
+                if (q == len) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) xT[i] = x[q][i];
+                }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) e[i] = xT[i] - Rt[(T1 * NX + i) * TILE];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                if (DIAG) {
+                    Vx[i] = p.Qf2[i * NX + i] * e[i];
+                } else {
+                    T s = p.Qf2[i * NX] * e[0];
+#pragma unroll
+                    for (int j = 1; j < NX; ++j) s = fma_(p.Qf2[i * NX + j], e[j], s);
+                    Vx[i] = s;
+                }
+#pragma unroll
+                for (int j = 0; j < NX; ++j) Vxx[i][j] = (DIAG && i != j) ? T(0) : p.Qf2[i * NX + j];
+            }
+        }
+#pragma unroll
+        for (int q = S - 1; q >= 0; --q) {
+            if (GUARD && q >= len) continue;
+            const int t = t0 + q;
+            T Kt[NU][NX], kt[NU];
+            status |= riccati_step<T, M, DIAG, CONSTR, FAST, (SHARED && FAST)>(p, t, x[q], cur.u[q], cur.xr[q], T(0), T(0), T(0), Vx, Vxx, Kt, kt, bad,
+                                                                               ss[q], cc[q]);
+            if (!PRED || store) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    kp[(t * NU + i) * TILE] = kt[i];
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) Kp[((t * NU + i) * NX + j) * TILE] = Kt[i][j];
+                }
+            }
+        }
+        cur = nxt;
+    };
+    segment(nseg - 1, std::true_type());
+    for (int seg = nseg - 2; seg >= 0; --seg) segment(seg, std::false_type());
+    return status;
+}
+
+// The backward pass of the problem in slot b0 under Params::lazy: problems with the mark are
+// regenerated (all of them, normally: one sweep); the others hold every state row in X, which need
+// not be a rollout, and take the reading sweep in a second, predicated pass of the wave.
+template <typename T, class M, bool DIAG, int CONSTR, int PF, class P>
+__device__ __forceinline__ void backward_body_gen(const P &p, int b0) {
+    constexpr int NX = M::NX, NU = M::NU;
+    const int nsl = slot_count(p);
+    if (nsl <= 0) return;
+    const bool valid = b0 < nsl;
+    const int o = orig_of(p, valid ? b0 : nsl - 1);
+    const bool active = valid && p.converged[o] == 0;
+    if (__ballot(active) == 0ull) return;
+    const int T1 = p.N - 1;
+    const int tile = b0 >> 6, ln = b0 & 63; // buffers are padded to whole tiles
+    const T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
+    const T *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
+    const T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
+    T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
+    T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    // (the padding lanes of the last tile go with the regenerating sweep: whatever they compute stays in the padding)
+    const bool regen = !valid || (p.slow_trig[o] & SLOW_TRIG_REGEN) != 0;
+    const bool whole = valid && !regen;
+    bool bad = false;
+    int status = 0;
+    // every lane stores, as in backward_sweep: a converged problem with the mark regenerates the
+    // trajectory of its last backward pass and rewrites the same bits; the lanes without the mark
+    // write gains of no meaning here and their own in the second pass
+    if (__ballot(regen) != 0ull) status = backward_sweep_gen<T, M, DIAG, CONSTR, true, false>(p, Xt, Rt, Ut, Kp, kp, bad, true);
+    if (__ballot(whole) != 0ull) {
+        bool bad1 = false;
+        const int status1 = backward_sweep<T, M, DIAG, CONSTR, PF, true, false, true>(p, Xt, Rt, Ut, nullptr, nullptr, Kp, kp, bad1, whole);
+        status = whole ? status1 : status;
+        bad = whole ? bad1 : bad;
+    }
+    // the fallbacks act per problem, as in backward_body
+    const bool redo = bad && valid;
+    if (__ballot(redo) != 0ull) {
+        int status2 = 0;
+        bool bad2 = false;
+        if (__ballot(redo && regen) != 0ull)
+            status2 = backward_sweep_gen<T, M, DIAG, CONSTR, false, true>(p, Xt, Rt, Ut, Kp, kp, bad2, redo && regen);
+        if (__ballot(redo && whole) != 0ull) {
+            const int status3 = backward_sweep<T, M, DIAG, CONSTR, 1, false>(p, Xt, Rt, Ut, nullptr, nullptr, Kp, kp, bad2, redo && whole);
+            status2 = whole ? status3 : status2;
+        }
+        status = redo ? status2 : status;
+    }
+    if (active && status != 0 && p.status) p.status[o] |= status;
+}
+
+template <typename T, class M, bool DIAG, int CONSTR, int PF>
+__global__ __launch_bounds__(64) void backward_gen_kernel(Params<T, M::NX, M::NU> p) {
+    backward_body_gen<T, M, DIAG, CONSTR, PF>(p, blockIdx.x * 64 + threadIdx.x);
+}
+
+// Fills in the state rows a sparse commit left out: for every problem with the mark, X[t+1] =
+// f(X[t], U[t]) from X[0] by the commit's instruction sequence (one lane per problem; the mark stays:
+// what it says remains true).
+template <typename T, class M> __global__ __launch_bounds__(64) void states_kernel(Params<T, M::NX, M::NU> p) {
+    constexpr int NX = M::NX, NU = M::NU, PF = 4;
+    const int b0 = blockIdx.x * 64 + threadIdx.x;
+    const int nsl = slot_count(p);
+    if (nsl <= 0) return;
+    const bool valid = b0 < nsl;
+    const int o = orig_of(p, valid ? b0 : nsl - 1);
+    const bool fill = valid && (p.slow_trig[o] & SLOW_TRIG_REGEN) != 0;
+    if (__ballot(fill) == 0ull) return;
+    const int T1 = p.N - 1;
+    const int tile = b0 >> 6, ln = b0 & 63;
+    T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
+    const T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
+    T x[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = Xt[i * TILE];
+    T ring[PF][NU];
+#pragma unroll
+    for (int s = 0; s < PF; ++s)
+#pragma unroll
+        for (int i = 0; i < NU; ++i) ring[s][i] = Ut[((s < T1 ? s : T1 - 1) * NU + i) * TILE];
+    bool bad = false;
+    for (int tb = 0; tb < T1; tb += PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            const int t = tb + s;
+            if (t >= T1) break;
+            T u[NU], xn[NX], sn = T(0), cn = T(0);
+#pragma unroll
+            for (int i = 0; i < NU; ++i) u[i] = ring[s][i];
+            const int tn = t + PF < T1 ? t + PF : T1 - 1;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) ring[s][i] = Ut[(tn * NU + i) * TILE];
+            model_step<true, false, M>(p, t, x, u, xn, sn, cn, bad);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = xn[i];
+            if (fill) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) Xt[((t + 1) * NX + i) * TILE] = xn[i];
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------- backward pass, n = 12, m = 4, fp64
@@ -1809,7 +2028,7 @@ __device__ __forceinline__ void evaluate_body(const P &p, int end, int wave, int
     if (active && al == 0 && !more) {
         p.alpha_idx[o] = found ? best : -1;
         p.Jtry[o] = best_cost;
-        p.slow_trig[o] = (p.slow_trig[o] & 6) | (pbad ? 1 : 0);
+        p.slow_trig[o] = (p.slow_trig[o] & (6 | SLOW_TRIG_REGEN)) | (pbad ? 1 : 0);
     }
 }
 
@@ -2097,7 +2316,7 @@ __global__ __launch_bounds__(64) void evaluate_listed_kernel(Params<T, M::NX, M:
         if (active && al == 0) {
             p.alpha_idx[o] = found ? best : -1;
             p.Jtry[o] = best_cost;
-            p.slow_trig[o] = (p.slow_trig[o] & 6) | (pbad ? 1 : 0);
+            p.slow_trig[o] = (p.slow_trig[o] & (6 | SLOW_TRIG_REGEN)) | (pbad ? 1 : 0);
         }
         return;
     }
@@ -2328,7 +2547,8 @@ template <typename T> __global__ __launch_bounds__(1024) void ltv12x4_evaluate_m
 // TC: the sine/cosine pair of every step of the trajectory being written goes to SCt (Params::SC),
 // and with REROLL the old trajectory's pairs are read from there first.
 // PF: rows of the next PF time steps are in flight while a step is computed.
-template <typename T, class M, int PF, bool REROLL, bool FAST, bool TC = false, class P>
+// LAZY (with REROLL, fast sweep only): of the states only the rows XCK, 2 XCK .. are stored.
+template <typename T, class M, int PF, bool REROLL, bool FAST, bool TC = false, bool LAZY = false, class P>
 __device__ __forceinline__ void commit_sweep(const P &p, T *Xt, T *Ut, const T *Kp, const T *kp, T *trash, T alpha, bool roll,
                                              bool keep_ok, bool pend, bool mute, T *SCt = nullptr) {
     constexpr int NX = M::NX, NU = M::NU;
@@ -2370,13 +2590,15 @@ __device__ __forceinline__ void commit_sweep(const P &p, T *Xt, T *Ut, const T *
         for (int i = 0; i < NX; ++i) xlast[i] = Xt[(T1 * NX + i) * TILE];
     }
     bool bad = false, badq = false;
-    for (int tb = 0; tb < T1; tb += PF) {
+    static_assert(!LAZY || (REROLL && FAST && XCK % PF == 0), "sparse states: fast sweep over recomputed previous states");
+    constexpr int UNR = LAZY ? XCK : PF; // steps per trip: which step stores a state row is then known at compile time
+    for (int tb = 0; tb < T1; tb += UNR) {
 #pragma unroll
-        for (int sl = 0; sl < PF; ++sl) {
+        for (int sl = 0; sl < UNR; ++sl) {
             const int t = tb + sl;
             if (t >= T1) break;
-            Row r = ring[sl];
-            if (t + PF < T1) load_row(t + PF, ring[sl]);
+            Row r = ring[sl % PF];
+            if (t + PF < T1) load_row(t + PF, ring[sl % PF]);
             const Row &nxt = ring[(sl + 1) % PF]; // row t+1 (if there is one)
             if (REROLL) {
 #pragma unroll
@@ -2412,6 +2634,7 @@ __device__ __forceinline__ void commit_sweep(const P &p, T *Xt, T *Ut, const T *
             // the recomputed old states are the stored ones only while the fast trigonometry was in
             // range (the library routine may differ from it in the last bit)
             const bool real = !mute && (roll || (!pend && FAST && keep_ok && !badq));
+            if (LAZY && sl != XCK - 1) continue; // row t+1 is not one of the rows a sparse commit keeps
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 if (REROLL) {
@@ -2426,7 +2649,7 @@ __device__ __forceinline__ void commit_sweep(const P &p, T *Xt, T *Ut, const T *
     }
 }
 
-template <typename T, class M, int PF, bool REROLL, bool TC = false>
+template <typename T, class M, int PF, bool REROLL, bool TC = false, bool LAZY = false>
 __global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, int it) {
     constexpr int NX = M::NX, NU = M::NU;
     const int b0 = blockIdx.x * 64 + threadIdx.x;
@@ -2456,11 +2679,13 @@ __global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, i
     // stored states = this code's fast-path rollout of the stored inputs
     const bool keep_ok = !valid || (slow_bits & 6) == 4;
     if (valid && !pend) {
-        const int committed = roll ? (4 | (slow ? 2 : 0)) : 0;
+        // (SLOW_TRIG_REGEN: this commit's trajectory is the fast-path rollout of its inputs; the sweep with
+        // the library routine writes every state row, and a problem that is not rolled out keeps its mark)
+        const int committed = roll ? (4 | (slow ? 2 : 0)) : 0, regen = (p.lazy && roll && !slow) ? SLOW_TRIG_REGEN : 0;
         if (!REROLL)
-            p.slow_trig[b] = (slow_bits & 1) | committed;
+            p.slow_trig[b] = (slow_bits & 1) | committed | regen;
         else if (roll)
-            p.slow_trig[b] = slow_bits | committed;
+            p.slow_trig[b] = ((slow_bits | committed) & ~SLOW_TRIG_REGEN) | regen;
     }
     if (active && !pend) {
         p.iters[b] += 1;
@@ -2483,7 +2708,7 @@ __global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, i
     // the fast sweep writes nothing for a problem that needs the library routine, and the second
     // sweep (rare) writes only those, so a problem's result does not depend on its wave-mates.
     T *SCt = TC ? tile_ptr(p.SC, tile, T1 * 2, ln) : nullptr;
-    commit_sweep<T, M, PF, REROLL, true, TC>(p, Xt, Ut, Kp, kp, trash, alpha, roll && !slow, keep_ok, pend, slow, SCt);
+    commit_sweep<T, M, PF, REROLL, true, TC, LAZY>(p, Xt, Ut, Kp, kp, trash, alpha, roll && !slow, keep_ok, pend, slow, SCt);
     if (__ballot(slow) != 0ull)
         commit_sweep<T, M, 1, REROLL, false, TC>(p, Xt, Ut, Kp, kp, trash, alpha, slow, keep_ok, pend, !slow, SCt);
 }

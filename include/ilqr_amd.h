@@ -93,7 +93,13 @@ typedef struct ilqr_desc {
                                   ilqr_workspace_bytes); 0 = auto (8 for B >= 32768, else never); < 0 = never */
     int32_t recompute_states;  /* >= 0: once a step has been committed, the forward kernels roll the previous
                                   states out again from U instead of reading X (same bits, less traffic);
-                                  < 0: always read X */
+                                  < 0: always read X.  Sparse states on top of that: between a commit and the
+                                  next backward pass only every 8th state row is stored and the backward pass
+                                  regenerates the others segment by segment (same bits; 11 200 of the 60 600
+                                  bytes the two passes move per Car problem less): 0 = inside ilqr_solve for
+                                  B >= 32768 (X is complete when it returns), 1 = never, 2 = always, also
+                                  between the phase calls (then read X only after ilqr_states).  Small models
+                                  (n <= 8), unconstrained, without trig_cache / segment_commit / overlap_stages. */
     int32_t overlap_stages;    /* > 0: the second line-search stage also commits its problems and runs beside the
                                   commit of the others, on a stream of the handle's own (ilqr_forward_commit then
                                   launches it; ilqr_forward_evaluate_stage 1 does nothing); <= 0 (default): it
@@ -172,6 +178,14 @@ int ilqr_bind(ilqr_handle *h, const ilqr_buffers *bufs);
  * Call it whenever X or U were written by anything but this library: it also tells the
  * handle that X is no longer known to be the rollout of U. */
 int ilqr_initial_cost(ilqr_handle *h, void *stream);
+/* Brings X up to date for a handle with recompute_states == 2, whose commits between phase calls
+ * store only every 8th state row (the backward pass and the line search regenerate what they need):
+ * call it before reading or rewriting X, and before ilqr_initial_cost / ilqr_solve (which start from
+ * a trajectory the caller may have written and return ILQR_ERR_INVALID while X is sparse).  A no-op
+ * otherwise; ilqr_solve leaves X complete, and ilqr_repack, ilqr_unpack and ilqr_shift, which move
+ * rows of X inside the iteration, fill it in themselves.  No reference counterpart
+ * (ilqr.py:62-63 stores every state as it goes). */
+int ilqr_states(ilqr_handle *h, void *stream);
 /* one backward pass for every non-converged problem: ilqr.py:76-105, cilqr.py:87-139 */
 int ilqr_backward(ilqr_handle *h, void *stream);
 /* one forward pass (line search) for every non-converged problem: ilqr.py:48-74.

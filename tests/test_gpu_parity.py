@@ -1242,3 +1242,94 @@ def test_single_launch_solve_does_not_change_a_bit(ilqr_cls, oracle):
         outs.append(o)
     for key in ("states", "inputs", "min_cost", "iterations", "converge"):
         assert np.array_equal(getattr(outs[0], key), getattr(outs[1], key)), key
+
+
+def test_sparse_states_do_not_change_a_bit(ilqr_cls, oracle):
+    """With ``recompute_states=2`` (automatic inside ilqr_solve from 32768 problems on) a commit
+    stores only every 8th state row and the backward pass rolls each segment of 8 steps out again
+    before walking it backwards; X is filled in again before anything reads it.  Pure traffic
+    saving: states, inputs, gains, costs, histories and flags must equal the run that stores every
+    state, bit for bit - horizons with a last segment of every length, single- and two-stage
+    mappings, compaction, several streams, ragged batches, problems that converge at once on
+    states that are not a rollout, a heading outside the fast sine/cosine range, an indefinite Quu,
+    fp32, the phase calls, a second (continuing) call, a run-time compiled model."""
+    from ilqr_amd import problems
+    keys = ("states", "inputs", "min_cost", "iterations", "converge", "status")
+    for N, B in ((110, 150), (9, 70), (10, 70), (3, 9), (17, 64), (24, 65), (200, 131)):
+        p = problems.car_batch(B, N)
+        for b in range(3):
+            p["init_states"][b] = p["target_states"][b]
+            p["init_inputs"][b] = 0.0
+        if B > 7:
+            p["init_states"][7, :, 3] += 3.0e6
+            p["target_states"][7, :, 3] += 3.0e6
+        ref = _solve_batch(ilqr_cls, p, recompute_states=-1, repack_every=-1)
+        Kr, kr = ref.K.copy(), ref.k.copy()
+        assert np.array_equal(ref.states[:3], p["target_states"][:3])
+        for kw in (dict(), dict(lanes_per_problem=1, alphas_per_lane=6), dict(lanes_per_problem=1, alphas_per_lane=6, repack_every=3),
+                   dict(lanes_per_problem=2, alphas_per_lane=4, repack_every=2, n_streams=2), dict(lanes_per_problem=16, alphas_per_lane=1),
+                   dict(lanes_per_problem=1, alphas_per_lane=8, repack_every=1), dict(n_streams=3)):
+            o = _solve_batch(ilqr_cls, p, recompute_states=2, trig_cache=-1, segment_commit=-1, fused_solve=-1, **kw)
+            for key in keys:
+                assert np.array_equal(getattr(o, key), getattr(ref, key), equal_nan=True), (N, B, kw, key)
+            assert np.array_equal(o.alpha_history, ref.alpha_history), (N, B, kw)
+            assert np.array_equal(o.cost_history, ref.cost_history, equal_nan=True)
+            assert np.array_equal(o.K, Kr) and np.array_equal(o.k, kr), (N, B, kw)
+    # indefinite Quu: the fallback sweep regenerates too
+    pq = problems.car_batch(70, 50)
+    outs = []
+    for rs in (1, 2):
+        c2 = demo_car_system()
+        c2.set_cost(np.diag([50.0, 50.0, 1000.0, 0.0]), np.diag([-50.0, 1000.0]))
+        s = ilqr_cls(c2, pq["target_states"], c2.dt, history=True, recompute_states=rs, trig_cache=-1, segment_commit=-1, fused_solve=-1)
+        s.inputs, s.states, s.maxIter = pq["init_inputs"].copy(), pq["init_states"].copy(), 5
+        s()
+        outs.append(s)
+    assert (outs[0].status != 0).any()
+    for key in keys:
+        assert np.array_equal(getattr(outs[0], key), getattr(outs[1], key), equal_nan=True), key
+    assert np.array_equal(outs[0].K, outs[1].K, equal_nan=True)
+    # the phase calls, X read in the middle (ilqr_states) and at the end; then a continuing ilqr_solve
+    p = problems.car_batch(100, 90)
+    car = demo_car_system()
+    got = []
+    for rs in (1, 2):
+        o = ilqr_cls(car, p["target_states"], car.dt, history=True, recompute_states=rs, trig_cache=-1, segment_commit=-1, fused_solve=-1,
+                     lanes_per_problem=1, alphas_per_lane=6, repack_every=-1)
+        o.inputs, o.states, o.maxIter = p["init_inputs"].copy(), p["init_states"].copy(), 4
+        dev = o.upload()
+        dev.initial_cost()
+        mid = None
+        for it in range(6):
+            dev.backward()
+            dev.forward_evaluate()
+            dev.forward_commit(it)
+            if it == 3:
+                mid = dev.download_states()
+        o.download()
+        first = (o.states.copy(), o.inputs.copy(), o.min_cost.copy(), mid)
+        o()                                           # four more iterations through ilqr_solve
+        got.append(first + (o.states.copy(), o.inputs.copy(), o.min_cost.copy(), o.K.copy()))
+    for a, b in zip(got[0], got[1]):
+        assert np.array_equal(a, b)
+    # fp32
+    p = problems.car_batch(90, 70)
+    a = _solve_batch(ilqr_cls, p, recompute_states=1, dtype=np.float32, trig_cache=-1, segment_commit=-1, fused_solve=-1)
+    b = _solve_batch(ilqr_cls, p, recompute_states=2, dtype=np.float32, trig_cache=-1, segment_commit=-1, fused_solve=-1)
+    assert np.array_equal(a.states, b.states) and np.array_equal(a.inputs, b.inputs) and np.array_equal(a.min_cost, b.min_cost)
+    assert np.array_equal(a.K, b.K)
+    # a run-time compiled model (no shared sine/cosine pair: the Jacobians evaluate their own)
+    from ilqr_amd.user_models import KinematicBicycle
+    q = problems.bicycle_batch(33, 60)
+    outs = []
+    for rs in (1, 2):
+        s = KinematicBicycle()
+        s.set_cost(problems.BICYCLE_Q.copy(), problems.BICYCLE_R.copy())
+        s.set_control_limit(*problems.BICYCLE_LIMITS)
+        o = ilqr_cls(s, q["target_states"], s.dt, history=True, recompute_states=rs, segment_commit=-1, fused_solve=-1)
+        o.inputs, o.states = q["init_inputs"].copy(), q["init_states"].copy()
+        o()
+        outs.append(o)
+    for key in ("states", "inputs", "min_cost", "iterations", "converge"):
+        assert np.array_equal(getattr(outs[0], key), getattr(outs[1], key)), key
+    assert np.array_equal(outs[0].K, outs[1].K)
