@@ -16,8 +16,8 @@ communication on the solve path); ``--weak`` gives every rank its own ``--batch`
 instead.  The reported value is the whole-job rate.
 
 Prints ONE JSON line on rank 0 with the metric, a ``roofline`` object for the dominant kernel
-(the one with the largest total time; per-launch HIP-event timings taken inside the timed region,
-achieved = the bytes the kernel must move for the problems still iterating / its duration) and, at N=1, a ``cpu_baseline``
+(the one with the largest total time; per-launch HIP-event timings taken inside the timed region, on
+its first step, achieved = the bytes the kernel must move for the problems still iterating / its duration) and, at N=1, a ``cpu_baseline``
 object: the C oracle (a port of the reference's per-problem loop) timed on the host cores on
 a bounded sample of the same workload.
 """
@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--trig-cache", type=int, default=0, help="sine/cosine cache: 0 = the library's choice, -1 off, 1 on")
     ap.add_argument("--sparse-states", type=int, default=0,
                     help="commits keep every 8th state row only: 0 = what ilqr_solve picks (on from 32768 problems per GPU), -1 off, 1 on")
+    ap.add_argument("--event-steps", type=int, default=1,
+                    help="timed steps whose launches are bracketed by HIP events for the per-kernel table (0 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=65536, help="upper bound on problems in the CPU baseline sample")
     args = ap.parse_args()
@@ -153,10 +155,14 @@ def main():
     for _ in range(args.warmup):
         solve_step()
     barrier()
+    # HIP events bracket every launch of the first `event_steps` timed steps (an event record costs about
+    # 5.6 us on the stream, 0.8 ms per step of 150 bracketed launches; the other steps issue the
+    # same launches back to back, as ilqr_solve does)
     events = []
+    event_steps = args.steps if args.event_steps <= 0 else min(args.steps, args.event_steps)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        solve_step(events)
+    for i in range(args.steps):
+        solve_step(events if i < event_steps else None)
     barrier()
     dt_local = time.perf_counter() - t0
     tmax = torch.tensor([dt_local], dtype=torch.float64, device="cuda")
@@ -200,13 +206,13 @@ def main():
     units = {"backward": active, "evaluate_first": active, "evaluate_rest": listed, "commit": accepted}
     kernels = {}
     for name, ms in kt.items():
-        ms = np.array(ms).reshape(args.steps, max_iter)
+        ms = np.array(ms).reshape(event_steps, max_iter)
         live = units[name] > 0
         total_ms = ms[:, live].sum()
-        total_bytes = float(args.steps) * float((units[name][live] * ab_it[name][live]).sum())
+        total_bytes = float(event_steps) * float((units[name][live] * ab_it[name][live]).sum())
         kernels[name] = {
-            "launches": int(live.sum()) * args.steps,
-            "avg_ms": float(total_ms / max(1, live.sum() * args.steps)),
+            "launches": int(live.sum()) * event_steps,
+            "avg_ms": float(total_ms / max(1, live.sum() * event_steps)),
             "total_ms": float(total_ms),
             "achieved_GBs": float(total_bytes / (total_ms * 1e-3) / 1e9) if total_ms > 0 else 0.0,
             "bytes_per_problem": ab[name],
@@ -259,6 +265,7 @@ def main():
             "solve_achieved_GBs": float(args.steps * (active * (ab_it["backward"] + ab_it["evaluate_first"]) + listed * ab_it["evaluate_rest"]
                                                       + accepted * ab_it["commit"]).sum()
                                         / elapsed / 1e9) * world,   # rank 0's shard x ranks (shards are equal up to one tile)
+            "event_steps": event_steps,       # timed steps whose launches carry the HIP events the `kernels` table is made of
             "ilqr_solve_ms": ilqr_solve_ms,     # one ilqr_solve() call on the same inputs (host clock, rank 0, untimed region)
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -19,7 +19,7 @@ import json
 import os
 import sys
 
-NAMES = (("backward_kernel", "backward"), ("evaluate_listed_kernel", "evaluate_rest"), ("evaluate_kernel", "evaluate_first"),
+NAMES = (("backward_kernel", "backward"), ("backward_gen_kernel", "backward"), ("states_kernel", "states"), ("repack_move_kernel", "repack"), ("evaluate_listed_kernel", "evaluate_rest"), ("evaluate_kernel", "evaluate_first"),
          ("commit_kernel", "commit"), ("cost_kernel", "cost"), ("relayout_kernel", "relayout"))
 
 
