@@ -1255,9 +1255,9 @@ def test_sparse_states_do_not_change_a_bit(ilqr_cls, oracle):
     fp32, the phase calls, a second (continuing) call, a run-time compiled model."""
     from ilqr_amd import problems
     keys = ("states", "inputs", "min_cost", "iterations", "converge", "status")
-    for N, B in ((110, 150), (9, 70), (10, 70), (3, 9), (17, 64), (24, 65), (200, 131)):
+    for N, B in ((110, 150), (9, 70), (10, 70), (3, 9), (2, 3), (17, 64), (24, 65), (200, 131)):
         p = problems.car_batch(B, N)
-        for b in range(3):
+        for b in range(min(3, B - 1)):
             p["init_states"][b] = p["target_states"][b]
             p["init_inputs"][b] = 0.0
         if B > 7:
@@ -1265,7 +1265,7 @@ def test_sparse_states_do_not_change_a_bit(ilqr_cls, oracle):
             p["target_states"][7, :, 3] += 3.0e6
         ref = _solve_batch(ilqr_cls, p, recompute_states=-1, repack_every=-1)
         Kr, kr = ref.K.copy(), ref.k.copy()
-        assert np.array_equal(ref.states[:3], p["target_states"][:3])
+        assert np.array_equal(ref.states[:2], p["target_states"][:2])
         for kw in (dict(), dict(lanes_per_problem=1, alphas_per_lane=6), dict(lanes_per_problem=1, alphas_per_lane=6, repack_every=3),
                    dict(lanes_per_problem=2, alphas_per_lane=4, repack_every=2, n_streams=2), dict(lanes_per_problem=16, alphas_per_lane=1),
                    dict(lanes_per_problem=1, alphas_per_lane=8, repack_every=1), dict(n_streams=3)):
