@@ -72,6 +72,9 @@ def main():
                     help="commits keep every 8th state row only: 0 = what ilqr_solve picks (on from 32768 problems per GPU), -1 off, 1 on")
     ap.add_argument("--event-steps", type=int, default=1,
                     help="timed steps whose launches are bracketed by HIP events for the per-kernel table (0 = all)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 on a box with one GPU: every rank uses device 0 and the ranks meet over gloo (checks the "
+                         "sharding, the barriers and the reductions; the time it prints means nothing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=65536, help="upper bound on problems in the CPU baseline sample")
     args = ap.parse_args()
@@ -86,8 +89,10 @@ def main():
         if world == 1 and args.gpus > 1:
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
             sys.exit(2)
+    if args.rehearse:
+        local = 0
     torch.cuda.set_device(local)
-    idist.init_process_group("nccl" if world > 1 else None)
+    idist.init_process_group(("gloo" if args.rehearse else "nccl") if world > 1 else None)
 
     N = args.horizon
     first, B, B_total = bench_shard(args.batch, rank, world, args.weak)
