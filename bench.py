@@ -265,6 +265,11 @@ def main():
                 "frac": kernels[dominant]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_ms": kernels[dominant]["avg_ms"],
                 "bytes_per_problem_per_launch": ab[dominant],
+                # the line search is the one kernel here that is not bound by bandwidth: it issues fp64 vector
+                # instructions in 83 % of its wave cycles (counter summaries under profiles/); the fractions of
+                # the bandwidth-bound kernels are in `kernels`
+                "limiter": "fp64 vector issue" if dominant.startswith("evaluate") else "HBM bandwidth",
+                "hbm_frac_by_kernel": {k: v["achieved_GBs"] / HBM_PEAK_GBS for k, v in kernels.items()},
             },
             "kernels": kernels,
             "solve_achieved_GBs": float(args.steps * (active * (ab_it["backward"] + ab_it["evaluate_first"]) + listed * ab_it["evaluate_rest"]

@@ -1333,3 +1333,21 @@ def test_sparse_states_do_not_change_a_bit(ilqr_cls, oracle):
     for key in ("states", "inputs", "min_cost", "iterations", "converge"):
         assert np.array_equal(getattr(outs[0], key), getattr(outs[1], key)), key
     assert np.array_equal(outs[0].K, outs[1].K)
+
+
+def test_sparse_states_at_a_size_where_they_are_the_default(ilqr_cls):
+    """From 32768 problems on ilqr_solve keeps sparse states and compacts the active set by itself.
+    40000 problems with the default settings against the same solve with every state stored
+    (``recompute_states=1``): all outputs bit for bit, gains and cost history included."""
+    from ilqr_amd import problems
+    B = 40000
+    p = problems.car_batch(B, 200)
+    outs = []
+    for rs in (1, 0):
+        o = _solve_batch(ilqr_cls, p, recompute_states=rs)
+        outs.append((o.states.copy(), o.inputs.copy(), o.min_cost.copy(), o.iterations.copy(), o.converge.copy(), o.status.copy(),
+                     o.K.copy(), o.k.copy(), o.cost_history.copy(), o.alpha_history.copy()))
+        del o
+    assert outs[0][4].any() and not outs[0][4].all()
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert np.array_equal(a, b, equal_nan=True), i
