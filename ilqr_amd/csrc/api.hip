@@ -510,7 +510,7 @@ static HostCtx &phase_ctx(ilqr_handle *h) {
 // Calls that start from a trajectory the caller may have written: X filled in by the library now would
 // overwrite it, X left sparse would be read as it is; the caller says which by calling ilqr_states first.
 #define REQUIRE_STATES(h) \
-    if ((h)->whole.stale) return ILQR_ERR_INVALID; /* ilqr_states first: X holds only every 8th state row */
+    if ((h)->whole.stale) return ILQR_ERR_SPARSE_STATES;
 
 int ilqr_states(ilqr_handle *h, void *stream) {
     REQUIRE_BOUND(h); // (sparse states between phase calls imply a bound workspace: those calls need one)
@@ -958,6 +958,7 @@ const char *ilqr_strerror(int code) {
     case ILQR_ERR_NOT_BOUND: return "a required device buffer is not bound";
     case ILQR_ERR_HIP: return "HIP runtime error (see ilqr_last_hip_error)";
     case ILQR_ERR_TOO_LARGE: return "batch exceeds the static scratch of ilqr_solve_static (ILQR_STATIC_MAX_PROBLEMS problems)";
+    case ILQR_ERR_SPARSE_STATES: return "X holds only every 8th state row (recompute_states = 2): call ilqr_states first";
     default: return "unknown error code";
     }
 }

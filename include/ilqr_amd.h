@@ -49,7 +49,8 @@ typedef enum ilqr_status {
     ILQR_ERR_UNSUPPORTED = -2, /* combination not built (model/dtype/shape) */
     ILQR_ERR_NOT_BOUND = -3,   /* a required buffer was not bound */
     ILQR_ERR_HIP = -4,         /* a HIP runtime call failed (see ilqr_last_hip_error) */
-    ILQR_ERR_TOO_LARGE = -5    /* ilqr_solve_static: more problems than its static scratch holds */
+    ILQR_ERR_TOO_LARGE = -5,   /* ilqr_solve_static: more problems than its static scratch holds */
+    ILQR_ERR_SPARSE_STATES = -6 /* recompute_states == 2: X holds only every 8th state row; call ilqr_states first */
 } ilqr_status;
 
 /* device dynamics: systems.py:27-57 / :59-90 / :92-121; LTV has no reference counterpart */
@@ -181,7 +182,7 @@ int ilqr_initial_cost(ilqr_handle *h, void *stream);
 /* Brings X up to date for a handle with recompute_states == 2, whose commits between phase calls
  * store only every 8th state row (the backward pass and the line search regenerate what they need):
  * call it before reading or rewriting X, and before ilqr_initial_cost / ilqr_solve (which start from
- * a trajectory the caller may have written and return ILQR_ERR_INVALID while X is sparse).  A no-op
+ * a trajectory the caller may have written and return ILQR_ERR_SPARSE_STATES while X is sparse).  A no-op
  * otherwise; ilqr_solve leaves X complete, and ilqr_repack, ilqr_unpack and ilqr_shift, which move
  * rows of X inside the iteration, fill it in themselves.  No reference counterpart
  * (ilqr.py:62-63 stores every state as it goes). */

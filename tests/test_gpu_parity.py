@@ -1305,6 +1305,10 @@ def test_sparse_states_do_not_change_a_bit(ilqr_cls, oracle):
             dev.forward_evaluate()
             dev.forward_commit(it)
             if it == 3:
+                if rs == 2:   # X is sparse now: the calls that start from X refuse until ilqr_states has run
+                    assert dev.lib.ilqr_initial_cost(dev.handle, dev.stream()) == -6
+                    assert dev.lib.ilqr_solve(dev.handle, 1, dev.stream()) == -6
+                    assert b"ilqr_states" in dev.lib.ilqr_strerror(-6)
                 mid = dev.download_states()
         o.download()
         first = (o.states.copy(), o.inputs.copy(), o.min_cost.copy(), mid)
