@@ -120,6 +120,23 @@ def test_auto_choices_and_workspace_of_a_handle():
     rc, h = _create(_desc(alpha_floor=1e-2, B=65536))
     assert rc == 0 and mapping(h) == (1, 8)          # 8 step sizes (cilqr.py:41): a single stage
     lib.ilqr_destroy(h)
+    # 8193 .. 16384 problems: ilqr_solve runs in one launch, built on the time-parallel commit, whose
+    # candidate checkpoints the workspace then holds; switched off, neither
+    ck = 16384 * 7 * 16 * 4 * 8
+    rc, h = _create(_desc(B=16384, N=200))
+    with_ck = lib.ilqr_workspace_bytes(h)
+    lib.ilqr_destroy(h)
+    rc2, h = _create(_desc(B=16384, N=200, fused_solve=-1))
+    without = lib.ilqr_workspace_bytes(h)
+    lib.ilqr_destroy(h)
+    assert rc == 0 and rc2 == 0 and with_ck - without == ck
+    rc, h = _create(_desc(B=16384, N=200, fused_solve=1, segment_commit=-1))   # asked for, but without what it is built on
+    assert rc == 0 and lib.ilqr_workspace_bytes(h) == without
+    lib.ilqr_destroy(h)
+    # sparse states need no workspace of their own; the calls around them exist and refuse unbound handles
+    rc, h = _create(_desc(B=65536, N=200, recompute_states=2, repack_every=-1))
+    assert rc == 0 and lib.ilqr_workspace_bytes(h) == small and lib.ilqr_states(h, None) == -3
+    lib.ilqr_destroy(h)
 
 
 def test_systems_interface_matches_reference_surface():
