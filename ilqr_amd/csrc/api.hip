@@ -315,9 +315,15 @@ int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
             L = 1;
             while (L < 8 && (long)d.B * L < 65536L) L *= 2;
             A = 8 / L;
-            // with a tile per SIMD or more, six candidates in the first stage are the better split
-            // (the accepted step is below index 6 in about 95 % of the line searches)
-            if (L == 1 && na > 8) A = 6;
+            // More than eight step sizes (ilqr.py:71: 15): six candidates in the first stage are the better
+            // split (the accepted step is below index 6 in about 98 % of the line searches that accept one),
+            // on one lane per problem while that fills the chip, on two lanes with three each below (measured,
+            // ms per solve of 24576 / 32768 / 49152 problems: (4,2) or (2,4) 21.4 / 20.9 / 27.9, (2,3) 17.9 /
+            // 19.9 / 27.2, (1,6) 20.4 / 20.8 / 26.2); the same split the compacted working set uses
+            if (na > 8) {
+                L = d.B < 40960 ? 2 : 1;
+                A = 6 / L;
+            }
             // Eight step sizes or fewer (cilqr.py:41) up to 16384 problems: a lane per candidate.  These
             // solves run up to 100 iterations, most of them for a few stragglers, where only the length
             // of a lane's serial rollout counts (measured at 16384 problems with box QP and barrier:
@@ -330,10 +336,9 @@ int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
             // throughput, and the second stage costs a whole rollout for a few problems: sixteen
             // candidates in a single stage are faster (measured at 4096 / 8192 / 16384 problems:
             // 13.4 -> 10.7, 13.6 -> 11.8, 17.3 -> 15.9 ms per solve; at 32768 two stages win)
+            // (lanes per problem by batch size, measured: (8,2) / (4,4) at 8192 problems 9.8 / 11.6 ms, at 9216: 14.7 / 12.4)
             if (na > 8 && na <= 16 && d.B <= 16384) {
-                L = 1;
-                while (L < 16 && (long)d.B * L < 65536L) L *= 2;
-                if (L < 4) L = 4;
+                L = d.B <= 4096 ? 16 : d.B <= 8192 ? 8 : 4;
                 A = 16 / L;
             }
         }

@@ -113,7 +113,7 @@ def test_auto_choices_and_workspace_of_a_handle():
     rc, h = _create(_desc(B=4096, N=200, trig_cache=-1, segment_commit=-1))
     assert rc == 0 and lib.ilqr_workspace_bytes(h) < 4096 * 200 * 4 * 8   # neither of them: per-problem scalars only
     lib.ilqr_destroy(h)
-    for B, want in ((8192, (8, 2)), (16384, (4, 4)), (32768, (2, 4))):
+    for B, want in ((8192, (8, 2)), (12288, (4, 4)), (16384, (4, 4)), (24576, (2, 3)), (32768, (2, 3)), (40960, (1, 6))):
         rc, h = _create(_desc(B=B, N=200))
         assert rc == 0 and mapping(h) == want
         lib.ilqr_destroy(h)
