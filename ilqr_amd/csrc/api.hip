@@ -54,10 +54,11 @@ static thread_local int g_last_hip_error = 0;
 
 // Batch sizes for which ilqr_solve chooses the single-launch solve by itself.  Measured (Car, N = 200,
 // ms per solve, launch per phase -> single launch): 4096 problems 7.35 -> 7.85, 8192: 9.81 -> 9.82,
-// 16384: 14.43 -> 13.78, 32768: 21.2 -> 24.1.  A workgroup's iteration is the same three serial sweeps
+// 16384: 14.43 -> 13.78, 32768: 21.2 -> 24.1; against the phase launches WITH the time-parallel commit,
+// (4,4) mapping: 9216 problems 11.8 -> 12.4, 10240: 12.4 -> 12.6, 12288: 13.0 -> 12.9.  A workgroup's iteration is the same three serial sweeps
 // either way; what the single launch saves is the gaps and tails of 90 launches, what it costs is
 // shallower prefetching (its phases share one register budget).
-constexpr int FUSED_AUTO_MIN = 8193, FUSED_AUTO_MAX = 16384;
+constexpr int FUSED_AUTO_MIN = 12288, FUSED_AUTO_MAX = 16384;
 
 // ---- scratch of ilqr_solve_static ---------------------------------------------------------------
 // One array per GPU, in the library's own device image, so that the entry point never allocates.
@@ -394,8 +395,8 @@ int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
     // commit, for unconstrained problems and the mappings with 16 candidates per round.
     const bool fused_ok = seg_ok && ops->solve != nullptr && (d.constraint_mode & 3) == 0 && L * A == 16 && d.segment_commit >= 0;
     h->fused = fused_ok && (d.fused_solve > 0 || (d.fused_solve == 0 && d.B >= FUSED_AUTO_MIN && d.B <= FUSED_AUTO_MAX));
-    h->seg = seg_ok && (h->fused || d.segment_commit > 0 || (d.segment_commit == 0 && d.B <= (d.constraint_mode != 0 ? 16384 : 8192)));
-    // (unconstrained at 16384: 14.6 against 14.5 ms, no gain; the constrained solver's long tail of
+    h->seg = seg_ok && (h->fused || d.segment_commit > 0 || (d.segment_commit == 0 && d.B <= (d.constraint_mode != 0 ? 16384 : 12288)));
+    // (unconstrained: 9216 problems 12.9 -> 11.8 ms, 12288: 13.7 -> 13.0, at 16384: 14.6 against 14.5 ms, no gain; the constrained solver's long tail of
     // iterations with few active problems gains at 16384 too: 58.0 -> 55.2 ms)
     h->ctx.seg = h->seg;
     // Sparse states (recompute_states: 0 = auto, 1 = never, 2 = everywhere).  They save traffic, which

@@ -115,13 +115,13 @@ typedef struct ilqr_desc {
     int32_t segment_commit;    /* > 0: the line search keeps the state of every candidate every 32 time steps in `work`
                                   and the commit rolls the accepted candidate out in all segments of 32 steps at once
                                   (same bits; the sequential commit leaves a small batch's chip idle for N-1 dependent
-                                  steps); 0 = auto (on up to 8192 problems); < 0: off.  Needs a single-stage line
+                                  steps); 0 = auto (on up to 12288 problems); < 0: off.  Needs a single-stage line
                                   search with 4 or more lanes per problem, n <= 8, no compaction, one stream. */
     int32_t fused_solve;       /* > 0: ilqr_solve runs all iterations in ONE launch in which a workgroup owns
                                   256 / lanes_per_problem problems from the first backward pass to the last commit
                                   (same bits as the launch-per-phase path; the latency-bound sweeps of some
                                   workgroups overlap the line searches of others, and a workgroup whose problems
-                                  have all converged leaves); 0 = auto (on for small batches); < 0: off.  Needs what
+                                  have all converged leaves); 0 = auto (12288 .. 16384 problems); < 0: off.  Needs what
                                   segment_commit needs, and unconstrained problems; forces segment_commit on when
                                   asked for explicitly.  The phase calls (ilqr_backward, ...) are not affected. */
     double dt;               /* system.dt (systems.py:30); the solver's own dt argument is unused (ilqr.py:20) */

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--recompute", default="0,-1")
     ap.add_argument("--fused", default="-1", help="fused_solve values, e.g. -1,1")
     ap.add_argument("--trig", type=int, default=0, help="trig_cache (0 = the library's choice)")
+    ap.add_argument("--seg", type=int, default=0, help="segment_commit (0 = the library's choice)")
     ap.add_argument("--repack", type=int, default=-1, help="repack_every (-1 = never, 0 = the library's choice)")
     a = ap.parse_args()
     import torch
@@ -41,7 +42,7 @@ def main():
         for mp, ns, rc, fs in itertools.product(a.mappings.split(","), a.streams.split(","), a.recompute.split(","), a.fused.split(",")):
             L, A = (int(v) for v in mp.split("x"))
             opt = iterative_LQR(car, p["target_states"], 0.2, lanes_per_problem=L, alphas_per_lane=A, n_streams=int(ns),
-                                recompute_states=int(rc), repack_every=a.repack, fused_solve=int(fs), trig_cache=a.trig)
+                                recompute_states=int(rc), repack_every=a.repack, fused_solve=int(fs), trig_cache=a.trig, segment_commit=a.seg)
             opt.inputs, opt.states = p["init_inputs"], p["init_states"]
             dev = opt.upload()
             X0, U0 = dev.X.clone(), dev.U.clone()
