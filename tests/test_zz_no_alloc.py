@@ -34,7 +34,9 @@ def _run(B, N, static, work_null=False, **kw):
 def test_static_scratch_solve_equals_ilqr_solve_twice():
     import torch
     assert torch.cuda.is_available()
-    for B, N, kw in ((700, 90, dict()), (130, 50, dict(lanes_per_problem=1, alphas_per_lane=6))):
+    # (the second call is the smaller one; the third keeps sparse states, whose bookkeeping lives in the same scratch)
+    for B, N, kw in ((700, 90, dict()), (130, 50, dict(lanes_per_problem=1, alphas_per_lane=6)),
+                     (333, 70, dict(lanes_per_problem=2, alphas_per_lane=3, recompute_states=2))):
         ref, Kr, kr = _run(B, N, static=False, **kw)
         got, Kg, kg = _run(B, N, static=True, work_null=True, **kw)
         assert (ref.iterations > 2).any() and ref.converge.any()
