@@ -923,8 +923,8 @@ __global__ __launch_bounds__(64) void backward_kernel(Params<T, M::NX, M::NU> p)
 // forward from its stored first state under the stored inputs (the commit's instruction sequence, so
 // these are the states the commit had in registers), keeping the states and, for a model with a
 // shared sine/cosine pair, the pairs, and is then walked backwards by riccati_step.  The rows of the
-// segment after next are under way meanwhile.  PRED: only the lanes with `store` write their gains
-// (else every lane does, see backward_sweep).
+// segment that comes next are under way meanwhile.  PRED: only the lanes with `store` write their
+// gains (else every lane does, see backward_sweep).
 template <typename T, class M, bool DIAG, int CONSTR, bool FAST, bool PRED, class P>
 __device__ __forceinline__ int backward_sweep_gen(const P &p, const T *Xt, const T *Rt, const T *Ut, T *Kp, T *kp, bool &bad, bool store) {
     constexpr int NX = M::NX, NU = M::NU, S = XCK;
