@@ -237,13 +237,12 @@ def main():
             "problems_per_launch": float(units[name][live].mean()) if live.any() else 0.0,
         }
     dominant = max(kernels, key=lambda k: kernels[k]["total_ms"])
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(dominant, {}).get("bytes_per_launch")
-        except Exception:
-            traffic = None
+    # counter profiles of this very command, committed under profiles/ (tools/round_profile.sh: separate
+    # rocprofv3 --pmc passes); quoted only while they were taken from the kernel source in the tree
+    traffic_all = stamped_profile("hbm_traffic.json")
+    limits_all = stamped_profile("kernel_limits.json")
+    traffic = (traffic_all or {}).get(dominant, {}).get("bytes_per_launch")
+    limit = (limits_all or {}).get(dominant)
 
     out = None
     if rank == 0:
@@ -278,11 +277,12 @@ def main():
                 "frac": kernels[dominant]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_ms": kernels[dominant]["avg_ms"],
                 "bytes_per_problem_per_launch": ab[dominant],
-                # the line search is the one kernel here that is not bound by bandwidth: it issues fp64 vector
-                # instructions in 83 % of its wave cycles (counter summaries under profiles/); the fractions of
-                # the bandwidth-bound kernels are in `kernels`
-                "limiter": "fp64 vector issue" if dominant.startswith("evaluate") else "HBM bandwidth",
+                # what the counters say the kernel is bound by (share of its wave cycles that issue a vector
+                # instruction; tools/pmc_limits.py), null without a profile of the current kernel source
+                "limiter": limit["limiter"] if limit else None,
+                "valu_busy": limit["valu_busy"] if limit else None,
                 "hbm_frac_by_kernel": {k: v["achieved_GBs"] / HBM_PEAK_GBS for k, v in kernels.items()},
+                "limiter_by_kernel": ({k: limits_all[k]["limiter"] for k in kernels if k in limits_all} if limits_all else None),
             },
             "kernels": kernels,
             "solve_achieved_GBs": float(args.steps * (active * (ab_it["backward"] + ab_it["evaluate_first"]) + listed * ab_it["evaluate_rest"]
@@ -308,6 +308,25 @@ def bench_shard(batch, rank, world, weak):
     return first, count, batch
 
 
+def kernel_source_stamp():
+    """git's blob hash of ilqr_amd/csrc/kernels.hpp (what tools/pmc_traffic.py stamps its output with)."""
+    import hashlib
+    data = open(os.path.join(ROOT, "ilqr_amd", "csrc", "kernels.hpp"), "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def stamped_profile(name):
+    """profiles/<name> if it was taken from the kernel source in the tree, else None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            prof = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if prof.get("_source", {}).get("kernels_hpp") != kernel_source_stamp():
+        return None
+    return prof
+
+
 def reference_calibration():
     """The measured ratio between the C port and the numpy reference (tools/time_reference.py, build
     container), or None if the file is absent."""
@@ -328,7 +347,11 @@ def cpu_baseline(car, p, N, sample):
     the same workload, OpenMP over problems on the host cores this process may use."""
     from oracle import oracle
     oracle.lib()
-    cores = min(16, len(os.sched_getaffinity(0)))
+    # every core this process may use, up to the worker count the box assigns to one GPU's job
+    # (OMP_NUM_THREADS there; the affinity mask shows the whole machine, which is shared)
+    avail = len(os.sched_getaffinity(0))
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    cores = min(avail, share) if share > 0 else avail
     d = oracle.make_desc(car, N)
     tg = np.ascontiguousarray(p["target_states"][:64])
     # scale the sample so the run takes roughly 30 core-seconds of CPU work in total
@@ -343,7 +366,7 @@ def cpu_baseline(car, p, N, sample):
     t0 = time.perf_counter()
     r = oracle.solve_batch(d, tg[:sample], st, ui, nthreads=cores, history=False)
     el = time.perf_counter() - t0
-    out = {"value": sample / el, "unit": "solves/s", "cores": cores, "kind": "port",
+    out = {"value": sample / el, "unit": "solves/s", "cores": cores, "cores_available": avail, "kind": "port",
            "sample": f"first {sample} problems of the same batch, C oracle (scalar fp64 port of ilqr.py), "
                      f"OpenMP over problems, {el:.1f} s wall, mean {float(r['iters'].mean()):.1f} iterations"}
     cal = reference_calibration()

@@ -76,6 +76,7 @@ _SIGNATURES = {
     "ilqr_unpack": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ilqr_shift": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "ilqr_forward_mapping": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "ilqr_sparse_states": (C.c_int32, [C.c_void_p]),
     "ilqr_forward_commit": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "ilqr_solve": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "ilqr_solve_static": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
@@ -84,6 +85,9 @@ _SIGNATURES = {
     "ilqr_active_count": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "ilqr_to_tiled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ilqr_from_tiled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "ilqr_to_tiled_v": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "ilqr_from_tiled_v": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "ilqr_gain_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ilqr_load_model": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
     "ilqr_model_dims": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ilqr_model_probe": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

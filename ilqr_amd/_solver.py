@@ -208,6 +208,7 @@ class DeviceProblem:
         flags stay where they are."""
         if self.hist_cost is not None and max_iter > self.hist_cost.shape[0]:
             torch = _torch()
+            self.fill_states()   # (binding again makes the library forget that X holds sparse rows)
             with torch.cuda.device(self.device):
                 self.hist_cost = torch.full((max_iter, self.B), float("nan"), dtype=self.t_dtype, device=self.device)
                 self.hist_alpha = torch.full((max_iter, self.B), -2, dtype=torch.int32, device=self.device)
@@ -237,18 +238,26 @@ class DeviceProblem:
             src = host.to(device=self.device, dtype=self.t_dtype).reshape(self.B, rows).contiguous()
         else:
             a = np.ascontiguousarray(np.asarray(host, dtype=self.np_dtype).reshape(self.B, rows))
+            if not a.flags.writeable:   # (a view of a read-only array: torch wants to be able to write)
+                a = a.copy()
             src = torch.from_numpy(a).to(self.device)
         _lib.check(self.lib.ilqr_to_tiled(src.data_ptr(), tiled.data_ptr(), self.B, rows,
                                           self.np_dtype.itemsize, self.stream()), "ilqr_to_tiled")
         # `src` must outlive the asynchronous kernel: both run on the current stream, and torch's
         # caching allocator only reuses the block for later work on that same stream.
 
-    def _download(self, tiled, rows, shape):
+    def _download(self, tiled, rows, shape, vec=1):
         torch = _torch()
         dst = torch.empty(self.B * rows, dtype=self.t_dtype, device=self.device)
-        _lib.check(self.lib.ilqr_from_tiled(tiled.data_ptr(), dst.data_ptr(), self.B, rows,
-                                            self.np_dtype.itemsize, self.stream()), "ilqr_from_tiled")
+        _lib.check(self.lib.ilqr_from_tiled_v(tiled.data_ptr(), dst.data_ptr(), self.B, rows,
+                                              self.np_dtype.itemsize, vec, self.stream()), "ilqr_from_tiled_v")
         return dst.cpu().numpy().reshape(shape)
+
+    def gain_layout(self):
+        """Rows interleaved per problem in the device buffers K and k."""
+        vK, vk = C.c_int32(0), C.c_int32(0)
+        _lib.check(self.lib.ilqr_gain_layout(self.handle, C.byref(vK), C.byref(vk)), "ilqr_gain_layout")
+        return int(vK.value), int(vk.value)
 
     # -- data movement ------------------------------------------------------
     def upload(self, target_states, states, inputs, converged=None, centers=None, radius=None):
@@ -275,10 +284,11 @@ class DeviceProblem:
         return self._download(self.U, (self.N - 1) * self.m, (self.B, self.N - 1, self.m))
 
     def download_K(self):
-        return self._download(self.K, (self.N - 1) * self.m * self.n, (self.B, self.N - 1, self.m, self.n))
+        return self._download(self.K, (self.N - 1) * self.m * self.n, (self.B, self.N - 1, self.m, self.n),
+                              vec=self.gain_layout()[0])
 
     def download_k(self):
-        return self._download(self.k, (self.N - 1) * self.m, (self.B, self.N - 1, self.m, 1))
+        return self._download(self.k, (self.N - 1) * self.m, (self.B, self.N - 1, self.m, 1), vec=self.gain_layout()[1])
 
     # -- solver phases (asynchronous on the current stream) -----------------
     def initial_cost(self):
@@ -309,6 +319,10 @@ class DeviceProblem:
         L, A = C.c_int32(0), C.c_int32(0)
         _lib.check(self.lib.ilqr_forward_mapping(self.handle, C.byref(L), C.byref(A)), "ilqr_forward_mapping")
         return int(L.value), int(A.value)
+
+    def sparse_states(self):
+        """0: commits store every state row; 1: every 8th inside ``solve`` only; 2: also between phase calls."""
+        return int(self.lib.ilqr_sparse_states(self.handle))
 
     def num_alphas(self):
         return int(self.lib.ilqr_num_alphas(self.handle))
@@ -458,6 +472,9 @@ class BatchedSolverBase:
                    converged=np.atleast_1d(np.asarray(self.converge)), **self._extra_upload())
         dev.iters.zero_()
         dev.status.zero_()
+        if dev.hist_cost is not None:   # (rows of an earlier call must not show through)
+            dev.hist_cost.fill_(float("nan"))
+            dev.hist_alpha.fill_(-2)
         self._k_cache = self._K_cache = None
         return dev
 
@@ -473,8 +490,9 @@ class BatchedSolverBase:
         it = dev.iters.cpu().numpy()
         stt = dev.status.cpu().numpy()
         if self._history:
-            self.cost_history = dev.hist_cost.cpu().numpy().T.copy()     # (B, maxIter)
-            self.alpha_history = dev.hist_alpha.cpu().numpy().T.copy()
+            mi = int(self.maxIter)   # (the buffers only ever grow)
+            self.cost_history = dev.hist_cost[:mi].cpu().numpy().T.copy()     # (B, maxIter)
+            self.alpha_history = dev.hist_alpha[:mi].cpu().numpy().T.copy()
         # the reference mutates the caller's arrays in place (ilqr.py:56, :62): write back into
         # the same objects when they are numpy arrays of the right shape
         if self._batched:

@@ -24,6 +24,7 @@ struct PartState {
     bool packed = false;
     bool stale = false; // a sparse commit has run since X was last filled in (HostCtx::lazy)
     int parity = 0;   // working set in use once packed
+    int gen = 0;      // generation of that working set: 1 for the first repack's, 2 for the next ..
 };
 
 struct ilqr_handle {
@@ -140,14 +141,16 @@ static int alphas_from_floor(double floor_) {
     return cnt;
 }
 
-template <bool TO_TILED> static int relayout(const void *src, void *dst, int B, int rows, int elem, void *stream) {
+template <bool TO_TILED> static int relayout(const void *src, void *dst, int B, int rows, int elem, int vec, void *stream) {
     if (!src || !dst || B <= 0 || rows <= 0) return ILQR_ERR_INVALID;
+    if ((vec != 1 && vec != 2 && vec != 4) || rows % vec != 0) return ILQR_ERR_INVALID;
+    const int vshift = vec == 4 ? 2 : vec == 2 ? 1 : 0;
     dim3 grid((rows + 63) / 64, (B + 63) / 64), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (elem == 8)
-        hipLaunchKernelGGL((relayout_kernel<double, TO_TILED>), grid, block, 0, s, (const double *)src, (double *)dst, B, rows);
+        hipLaunchKernelGGL((relayout_kernel<double, TO_TILED>), grid, block, 0, s, (const double *)src, (double *)dst, B, rows, vshift);
     else if (elem == 4)
-        hipLaunchKernelGGL((relayout_kernel<float, TO_TILED>), grid, block, 0, s, (const float *)src, (float *)dst, B, rows);
+        hipLaunchKernelGGL((relayout_kernel<float, TO_TILED>), grid, block, 0, s, (const float *)src, (float *)dst, B, rows, vshift);
     else
         return ILQR_ERR_INVALID;
     return hip_rc(hipGetLastError());
@@ -183,39 +186,6 @@ static hipError_t repack_launch(ilqr_handle *h, PartState &ps, int mode, hipStre
         hipLaunchKernelGGL(repack_scan_kernel, dim3(1), dim3(1024), 0, s, (const int32_t *)tile_count, tile_offset, ntiles, nslots_new);
     }
     RepackArgs<T> a;
-    a.narr = 0;
-    int chunks = 0;
-    auto add = [&](const void *src, T *dst_active, T *dst_retire, int rows) {
-        if (!dst_active && !dst_retire) return;
-        a.arr[a.narr].src = (const T *)src;
-        a.arr[a.narr].dst_active = dst_active;
-        a.arr[a.narr].dst_retire = dst_retire;
-        a.arr[a.narr].rows = rows;
-        a.arr[a.narr].chunk0 = chunks;
-        chunks += (rows + REPACK_CHUNK - 1) / REPACK_CHUNK;
-        ++a.narr;
-    };
-    const bool pk = ps.packed;
-    // current arrays: the caller's buffers until the first repack, a working set afterwards
-    const void *Xc = pk ? ps.ctx.ws.X : part_rel(b.X, N * n), *Uc = pk ? ps.ctx.ws.U : part_rel(b.U, T1 * m);
-    const void *Rc = pk ? ps.ctx.ws.Xref : part_rel(b.Xref, N * n);
-    const void *Cc = pk ? ps.ctx.ws.centers : part_rel(b.centers, N * 2), *Dc = pk ? ps.ctx.ws.radius : part_rel(b.radius, N);
-    if (mode == REPACK_RETIRE_LIVE) {
-        add(ps.ctx.ws.K, nullptr, (T *)b.K, T1 * m * n);
-        add(ps.ctx.ws.k, nullptr, (T *)b.k, T1 * m);
-    } else {
-        // retired problems go to their own place in the caller's buffers; before the first repack
-        // they are there already
-        add(Xc, carry ? set_ptr(q, 0, N * n) : nullptr, pk ? (T *)b.X : nullptr, N * n);
-        add(Uc, carry ? set_ptr(q, 1, T1 * m) : nullptr, pk ? (T *)b.U : nullptr, T1 * m);
-        if (carry) {
-            add(Rc, set_ptr(q, 2, N * n), nullptr, N * n);
-            if (barrier) {
-                add(Cc, set_ptr(q, 3, N * 2), nullptr, N * 2);
-                add(Dc, set_ptr(q, 4, N), nullptr, N);
-            }
-        }
-    }
     a.slot2orig_old = map_old;
     a.slot2orig_new = map_new;
     a.nslots_old = nslots_old;
@@ -225,10 +195,67 @@ static hipError_t repack_launch(ilqr_handle *h, PartState &ps, int mode, hipStre
     a.first = ps.ctx.first;
     a.mode = mode;
     a.carried = (int32_t *)(work + wl.carried);
+    a.orig2slot = (int32_t *)(work + wl.orig2slot);
+    const bool pk = ps.packed;
     a.first_repack = pk ? 0 : 1;
-    if (a.narr > 0) hipLaunchKernelGGL((repack_move_kernel<T>), dim3(ntiles, chunks), dim3(64), 0, s, a);
+    a.gen_prev = 0;
+    int chunks = 0;
+    auto add = [&](const void *src, T *dst_active, T *dst_retire, int rows, int vec = 1) {
+        a.arr[a.narr].vshift = vec == 4 ? 2 : vec == 2 ? 1 : 0;
+        a.arr[a.narr].src_prev = nullptr;
+        a.arr[a.narr].src = (const T *)src;
+        a.arr[a.narr].dst_active = dst_active;
+        a.arr[a.narr].dst_retire = dst_retire;
+        a.arr[a.narr].rows = rows;
+        a.arr[a.narr].chunk0 = chunks;
+        chunks += (rows + REPACK_CHUNK - 1) / REPACK_CHUNK;
+        ++a.narr;
+    };
+    // current arrays: the caller's buffers until the first repack, a working set afterwards
+    const void *Xc = pk ? ps.ctx.ws.X : part_rel(b.X, N * n), *Uc = pk ? ps.ctx.ws.U : part_rel(b.U, T1 * m);
+    const void *Rc = pk ? ps.ctx.ws.Xref : part_rel(b.Xref, N * n);
+    const void *Cc = pk ? ps.ctx.ws.centers : part_rel(b.centers, N * 2), *Dc = pk ? ps.ctx.ws.radius : part_rel(b.radius, N);
+    // destination-major: problems leave a working set for their own place in the caller's buffers (before
+    // the first repack they are there already).  States and inputs leave late: the problems that
+    // converge while a working set is the current one stay in it, and it is read out when the next but
+    // one generation is about to be built over it (a repack with ps.gen >= 2) or at the end of the
+    // solve, together with the current one; the two repacks of a 30-iteration solve retire nothing.
+    if (pk) {
+        a.narr = 0;
+        chunks = 0;
+        a.gen = ps.gen;
+        a.gen_prev = 0;
+        const int qp = 1 - ps.parity; // the set the generation before the current one lives in
+        if (mode == REPACK_RETIRE_LIVE) {
+            add(ps.ctx.ws.K, nullptr, (T *)b.K, T1 * m * n, gain_vec_of(n, n));
+            add(ps.ctx.ws.k, nullptr, (T *)b.k, T1 * m, gain_vec_of(m, n));
+        } else {
+            a.gen_prev = ps.gen >= 2 ? ps.gen - 1 : 0;
+            add(Xc, nullptr, (T *)b.X, N * n);
+            a.arr[a.narr - 1].src_prev = set_ptr(qp, 0, N * n);
+            add(Uc, nullptr, (T *)b.U, T1 * m);
+            a.arr[a.narr - 1].src_prev = set_ptr(qp, 1, T1 * m);
+        }
+        if (mode != REPACK_CARRY || a.gen_prev > 0)
+            hipLaunchKernelGGL((repack_retire_kernel<T>), dim3(ntiles, chunks), dim3(64), 0, s, a);
+    }
+    if (carry) {
+        // source-major: the active problems move on into the working set of the next generation
+        a.narr = 0;
+        chunks = 0;
+        a.gen = ps.gen + 1;
+        add(Xc, set_ptr(q, 0, N * n), nullptr, N * n);
+        add(Uc, set_ptr(q, 1, T1 * m), nullptr, T1 * m);
+        add(Rc, set_ptr(q, 2, N * n), nullptr, N * n);
+        if (barrier) {
+            add(Cc, set_ptr(q, 3, N * 2), nullptr, N * 2);
+            add(Dc, set_ptr(q, 4, N), nullptr, N);
+        }
+        hipLaunchKernelGGL((repack_move_kernel<T>), dim3(ntiles, chunks), dim3(64), 0, s, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !carry) return e;
+    ps.gen += 1;
     ps.ctx.ws.X = set_ptr(q, 0, N * n);
     ps.ctx.ws.U = set_ptr(q, 1, T1 * m);
     ps.ctx.ws.Xref = set_ptr(q, 2, N * n);
@@ -384,8 +411,11 @@ int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
     // by bandwidth, where 16 more bytes per step and pass cost more than the instructions saved.
     // Not with compaction (the cache is not carried into the working sets) nor beside a second
     // line-search stage that commits on its own.
+    // (sparse states asked for by value, recompute_states = 2, win over the automatic choice here and of
+    // the time-parallel commit below: the three exclude one another)
+    const bool want_sparse = d.recompute_states >= 2;
     h->trig = ops->trig_pairs == 1 && h->repack_every == 0 && d.recompute_states >= 0 && d.overlap_stages <= 0 &&
-              (d.trig_cache > 0 || (d.trig_cache == 0 && d.B <= 16384));
+              (d.trig_cache > 0 || (d.trig_cache == 0 && d.B <= 16384 && !want_sparse));
     h->ctx.trig = h->trig;
     // Time-parallel commit: 0 = auto, for the same batch sizes (one lane per problem leaves most of the
     // chip idle during the sequential commit); needs a single-stage line search with four or more
@@ -394,8 +424,9 @@ int ilqr_create(const ilqr_desc *desc, ilqr_handle **out) {
     // One launch for the whole solve (solve_owned_kernel): 0 = auto.  It is built on the time-parallel
     // commit, for unconstrained problems and the mappings with 16 candidates per round.
     const bool fused_ok = seg_ok && ops->solve != nullptr && (d.constraint_mode & 3) == 0 && L * A == 16 && d.segment_commit >= 0;
-    h->fused = fused_ok && (d.fused_solve > 0 || (d.fused_solve == 0 && d.B >= FUSED_AUTO_MIN && d.B <= FUSED_AUTO_MAX));
-    h->seg = seg_ok && (h->fused || d.segment_commit > 0 || (d.segment_commit == 0 && d.B <= (d.constraint_mode != 0 ? 16384 : 12288)));
+    h->fused = fused_ok && (d.fused_solve > 0 || (d.fused_solve == 0 && !want_sparse && d.B >= FUSED_AUTO_MIN && d.B <= FUSED_AUTO_MAX));
+    h->seg = seg_ok && (h->fused || d.segment_commit > 0 ||
+                        (d.segment_commit == 0 && !want_sparse && d.B <= (d.constraint_mode != 0 ? 16384 : 12288)));
     // (unconstrained: 9216 problems 12.9 -> 11.8 ms, 12288: 13.7 -> 13.0, at 16384: 14.6 against 14.5 ms, no gain; the constrained solver's long tail of
     // iterations with few active problems gains at 16384 too: 58.0 -> 55.2 ms)
     h->ctx.seg = h->seg;
@@ -440,6 +471,8 @@ int ilqr_forward_mapping(const ilqr_handle *h, int32_t *lanes_per_problem, int32
     return ILQR_OK;
 }
 
+int32_t ilqr_sparse_states(const ilqr_handle *h) { return h ? (h->lazy_calls ? 2 : h->lazy_solve ? 1 : 0) : 0; }
+
 int ilqr_bind(ilqr_handle *h, const ilqr_buffers *b) {
     if (!h || !b) return ILQR_ERR_INVALID;
     // `work` may be NULL for a caller that only uses ilqr_solve_static; every other call checks it
@@ -450,10 +483,16 @@ int ilqr_bind(ilqr_handle *h, const ilqr_buffers *b) {
     if (const LoadedModel *lm = loaded_model(h->ctx.d.model); lm && lm->info.needs_tables && (!b->ltv_A || !b->ltv_B))
         return ILQR_ERR_NOT_BOUND; // its kernels would read through a null pointer
     if ((b->hist_cost || b->hist_alpha) && b->hist_capacity <= 0) return ILQR_ERR_INVALID;
+    // X may hold only every 8th state row (sparse commits between phase calls) and the marks that say
+    // how to fill it in live in `work`: binding the same X again keeps that state (with another
+    // workspace the marks would be lost); binding another X starts afresh
+    const bool sparse_now = h->ctx.bound && h->whole.stale && b->X == h->ctx.b.X;
+    if (sparse_now && b->work != h->ctx.b.work) return ILQR_ERR_SPARSE_STATES;
     h->ctx.b = *b;
     h->ctx.bound = true;
     h->ctx.reroll = false;
     h->whole = PartState();
+    h->whole.stale = sparse_now;
     return ILQR_OK;
 }
 
@@ -557,7 +596,7 @@ int ilqr_forward_commit(ilqr_handle *h, int32_t iteration, void *stream) {
     if (iteration < 0) return ILQR_ERR_INVALID;
     if (hipError_t e = ensure_side(h); e != hipSuccess) return hip_rc(e);
     const int rc = hip_rc(h->ops->commit(phase_ctx(h), iteration, (hipStream_t)stream));
-    if (h->lazy_calls && h->ctx.reroll) h->whole.stale = true; // (a sparse commit, if the launch table has one for this handle)
+    if (rc == ILQR_OK && h->lazy_calls && h->ctx.reroll) h->whole.stale = true; // (a sparse commit, if the launch table has one for this handle)
     // every problem that is still active afterwards has had a step committed by this library
     if (rc == ILQR_OK && h->ctx.d.recompute_states >= 0) h->ctx.reroll = true;
     return rc;
@@ -576,6 +615,7 @@ int ilqr_unpack(ilqr_handle *h, void *stream) {
     const int rc = unpack(h, h->whole, (hipStream_t)stream);
     if (rc == ILQR_OK) {
         h->whole.packed = false;
+        h->whole.gen = 0;
         h->whole.ctx.ws = HostCtx::WorkSet();
     }
     return rc;
@@ -666,6 +706,7 @@ static int solve_impl(ilqr_handle *h, int32_t max_iter, void *work, bool compact
         }
     for (int s = 0; s < np; ++s) {
         if (rc == ILQR_OK) rc = unpack(h, part[s], st[s]); // retire what is still in a working set
+        else if (!part[s].packed) (void)fill_states(h, part[s], st[s]); // after an error: at least no sparse rows left behind
         if (np > 1 && s < forked) {
             e = hipEventRecord(h->join_event[s], st[s]);
             if (e == hipSuccess) e = hipStreamWaitEvent(user, h->join_event[s], 0);
@@ -767,11 +808,26 @@ int ilqr_shift(ilqr_handle *h, int32_t shift, const void *x0, void *stream) {
 }
 
 int ilqr_to_tiled(const void *aos, void *tiled, int32_t B, int32_t rows, int32_t elem_bytes, void *stream) {
-    return relayout<true>(aos, tiled, B, rows, elem_bytes, stream);
+    return relayout<true>(aos, tiled, B, rows, elem_bytes, 1, stream);
 }
 
 int ilqr_from_tiled(const void *tiled, void *aos, int32_t B, int32_t rows, int32_t elem_bytes, void *stream) {
-    return relayout<false>(tiled, aos, B, rows, elem_bytes, stream);
+    return relayout<false>(tiled, aos, B, rows, elem_bytes, 1, stream);
+}
+
+int ilqr_to_tiled_v(const void *aos, void *tiled, int32_t B, int32_t rows, int32_t elem_bytes, int32_t vec, void *stream) {
+    return relayout<true>(aos, tiled, B, rows, elem_bytes, vec, stream);
+}
+
+int ilqr_from_tiled_v(const void *tiled, void *aos, int32_t B, int32_t rows, int32_t elem_bytes, int32_t vec, void *stream) {
+    return relayout<false>(tiled, aos, B, rows, elem_bytes, vec, stream);
+}
+
+int ilqr_gain_layout(const ilqr_handle *h, int32_t *vec_K, int32_t *vec_k) {
+    if (!h || !vec_K || !vec_k) return ILQR_ERR_INVALID;
+    *vec_K = gain_vec_of(h->ctx.d.n, h->ctx.d.n);
+    *vec_k = gain_vec_of(h->ctx.d.m, h->ctx.d.n);
+    return ILQR_OK;
 }
 
 int ilqr_load_model(const char *path, int32_t *model_id) {

@@ -54,7 +54,7 @@ struct HostCtx {
 // exist; the rest only with active-set compaction.
 struct WorkLayout {
     size_t jtry = 0, slow = 0, counters = 0, list = 0, list_count = 0, trash = 0, redo = 0;
-    size_t map[2] = {0, 0}, tile_count = 0, tile_offset = 0, nslots = 0, carried = 0;
+    size_t map[2] = {0, 0}, tile_count = 0, tile_offset = 0, nslots = 0, carried = 0, orig2slot = 0;
     size_t set[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}; // X, U, Xref, centers, radius of the two working sets
     size_t Kw = 0, kw = 0;
     size_t sc = 0; // sine/cosine cache (only with `trig`; never together with compaction)
@@ -90,6 +90,7 @@ static inline WorkLayout work_layout(const ilqr_desc &d, bool compaction, bool t
         w.tile_offset = take(tiles * 4);
         w.nslots = take(256);
         w.carried = take((size_t)d.B * 4);
+        w.orig2slot = take((size_t)d.B * 4);
         for (int q = 0; q < 2; ++q) {
             w.set[q][0] = take(Bp * N * n * e);
             w.set[q][1] = take(Bp * T1 * m * e);
@@ -136,7 +137,7 @@ struct PluginInfo {
     const ModelOps *(*ops)(int dtype, bool diag);
     const SqpOps *(*sqp)(int dtype); // sequential-QP kernels for this model, or a function returning null
 };
-constexpr int32_t PLUGIN_ABI_VERSION = 6;
+constexpr int32_t PLUGIN_ABI_VERSION = 7;
 static inline int32_t plugin_abi() {
     return (int32_t)(PLUGIN_ABI_VERSION * 1000003u + sizeof(HostCtx) * 31u + sizeof(ilqr_desc) * 7u + sizeof(ilqr_buffers));
 }

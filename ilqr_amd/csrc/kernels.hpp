@@ -23,6 +23,8 @@
 #include <stdint.h>
 #include <type_traits>
 
+#include "fast_trig.hpp"
+
 namespace ilqr {
 
 // per-problem status bits (same values as ILQR_STATUS_* of the C header)
@@ -33,46 +35,16 @@ template <typename T> __device__ __forceinline__ T fma_(T a, T b, T c);
 template <> __device__ __forceinline__ double fma_<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
 template <> __device__ __forceinline__ float fma_<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-// fp64 sine and cosine of one angle, <= 1 ulp.  FAST: Cody-Waite reduction by pi/2 split into
-// three doubles (the products are exact inside the fused multiply-adds), then the fdlibm
-// minimax kernels on [-pi/4, pi/4] (S1..S6, C1..C6 of __kernel_sin/__kernel_cos, Sun
-// Microsystems, freely distributable) and a quadrant swap.  The fast form is branch-free so
-// that a whole time step stays one basic block the scheduler can interleave; it is valid for
-// |x| < 2^20 and reports anything else (larger arguments, infinities, NaN) in `bad`.  A kernel
-// that sees `bad` anywhere in a wave redoes its work with FAST = false, the library routine.
+// fp64 sine and cosine of one angle: FAST = the branch-free routine of fast_trig.hpp (valid for
+// |x| < 2^20, reports anything else in `bad`), else the library routine.  A kernel that sees `bad`
+// anywhere in a wave redoes its work with FAST = false.
 template <bool FAST> __device__ __forceinline__ void sincos_(double x, double &s, double &c, bool &bad) {
     if (!FAST) {
         sincos(x, &s, &c);
         return;
     }
-    bad = bad || !(__builtin_fabs(x) < 1048576.0);
-    const double q = __builtin_rint(x * 6.36619772367581382433e-01);
-    double r = __builtin_fma(q, -1.57079632679489655800e+00, x);
-    r = __builtin_fma(q, -6.12323399573676603587e-17, r);
-    r = __builtin_fma(q, 1.49738490485916983528e-33, r);
-    const int n = (int)q;
-    const double z = r * r;
-    // sin(r) = r + r^3 (S1 + z (S2 + ...))
-    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
-    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
-    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
-    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
-    const double sr = __builtin_fma(z * r, ps, r);
-    // cos(r) = 1 - z/2 + z^2 (C1 + z (C2 + ...)), with the rounding error of 1 - z/2 recovered
-    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
-    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
-    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
-    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
-    const double hz = 0.5 * z;
-    const double w = 1.0 - hz;
-    const double cr = w + (((1.0 - w) - hz) + z * (z * pc));
-    // quadrant: n mod 4 = 0: (s, c) ; 1: (c, -s) ; 2: (-s, -c) ; 3: (-c, s)
-    const double s0 = (n & 1) ? cr : sr;
-    const double c0 = (n & 1) ? sr : cr;
-    s = (n & 2) ? -s0 : s0;
-    c = ((n + 1) & 2) ? -c0 : c0;
+    const bool ok = fast_sincos(x, s, c); // (evaluated whatever `bad` holds: no branch)
+    bad = bad || !ok;
 }
 template <bool FAST> __device__ __forceinline__ void sincos_(float x, float &s, float &c, bool &) { sincosf(x, &s, &c); }
 __device__ __forceinline__ double log_(double x) { return log(x); }
@@ -118,6 +90,33 @@ constexpr int SLOW_TRIG_REGEN = 8; // bit of Params::slow_trig: rows 0, XCK, 2 X
 constexpr int CK_CANDIDATES = 16; // candidate slots per segment start
 template <typename T> __device__ __forceinline__ T *tile_ptr(T *base, int tile, int rows, int lane) {
     return base + (size_t)tile * (size_t)rows * TILE + lane;
+}
+// The gain arrays K and k of the lane-per-problem models (n <= 8) interleave V consecutive rows per
+// problem: [tile][row / V][64][V], i.e. V values of one problem side by side (V = 4 or 2 where the
+// row count per time step allows, K: the n entries of a gain row, k: the m entries of a step).  A
+// lane then moves 16 or 32 contiguous bytes where it moved V separate 8-byte pieces, and whoever
+// reads the gains of a single problem (the second line-search stage, the retirement of a working
+// set) touches a V-th of the 128-byte lines.  V = 1 is the plain tiled layout; the n = 12 kernels,
+// whose rows travel as whole lines of 16 problems, keep it.
+constexpr int gain_vec_of(int per_step, int nx) { return nx > 8 ? 1 : per_step % 4 == 0 ? 4 : per_step % 2 == 0 ? 2 : 1; }
+template <class M> struct GainLayout {
+    static constexpr int VK = gain_vec_of(M::NX, M::NX); // K: rows (t, i, j), j innermost
+    static constexpr int Vk = gain_vec_of(M::NU, M::NX); // k: rows (t, i)
+};
+// offsets from a problem's pointer (tile_ptr_v): K[t][i][j] and k[t][i] with ti = t * NU + i (written so
+// that the group index needs no division of a run-time value), and the flat row r of an array with V
+// interleaved rows
+template <class M> __device__ __forceinline__ constexpr size_t gain_K(int ti, int j) {
+    constexpr int V = GainLayout<M>::VK;
+    return (size_t)(ti * (M::NX / V) + j / V) * (size_t)(TILE * V) + (size_t)(j % V);
+}
+template <class M> __device__ __forceinline__ constexpr size_t gain_k(int t, int i) {
+    constexpr int V = GainLayout<M>::Vk;
+    return (size_t)(t * (M::NU / V) + i / V) * (size_t)(TILE * V) + (size_t)(i % V);
+}
+template <int V> __device__ __forceinline__ constexpr size_t vrow(int r) { return (size_t)(r / V) * (size_t)(TILE * V) + (size_t)(r % V); }
+template <int V, typename T> __device__ __forceinline__ T *tile_ptr_v(T *base, int tile, int rows, int lane) {
+    return base + (size_t)tile * (size_t)rows * TILE + (size_t)lane * V;
 }
 
 // ---------------------------------------------------------------- parameters
@@ -864,9 +863,9 @@ __device__ __forceinline__ int backward_sweep(const P &p, const T *Xt, const T *
             if ((FAST && !TC && !COND) || store) {
 #pragma unroll
                 for (int i = 0; i < NU; ++i) {
-                    kp[(t * NU + i) * TILE] = kt[i];
+                    kp[gain_k<M>(t, i)] = kt[i];
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) Kp[((t * NU + i) * NX + j) * TILE] = Kt[i][j];
+                    for (int j = 0; j < NX; ++j) Kp[gain_K<M>(t * NU + i, j)] = Kt[i][j];
                 }
             }
         }
@@ -894,8 +893,8 @@ __device__ __forceinline__ void backward_body(const P &p, int b0) {
     const T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
     const T *Cp = BARRIER_ ? tile_ptr(p.centers, tile, p.N * 2, ln) : nullptr;
     const T *Dp = BARRIER_ ? tile_ptr(p.radius, tile, p.N, ln) : nullptr;
-    T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
-    T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    T *kp = tile_ptr_v<GainLayout<M>::Vk>(p.k, tile, T1 * NU, ln);
+    T *Kp = tile_ptr_v<GainLayout<M>::VK>(p.K, tile, T1 * NU * NX, ln);
     const T *SCp = TC ? tile_ptr(p.SC, tile, T1 * 2, ln) : nullptr;
     bool bad = false;
     int status = backward_sweep<T, M, DIAG, CONSTR, PF, true, TC>(p, Xt, Rt, Ut, Cp, Dp, Kp, kp, bad, active, SCp);
@@ -1008,9 +1007,9 @@ __device__ __forceinline__ int backward_sweep_gen(const P &p, const T *Xt, const
             if (!PRED || store) {
 #pragma unroll
                 for (int i = 0; i < NU; ++i) {
-                    kp[(t * NU + i) * TILE] = kt[i];
+                    kp[gain_k<M>(t, i)] = kt[i];
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) Kp[((t * NU + i) * NX + j) * TILE] = Kt[i][j];
+                    for (int j = 0; j < NX; ++j) Kp[gain_K<M>(t * NU + i, j)] = Kt[i][j];
                 }
             }
         }
@@ -1038,8 +1037,8 @@ __device__ __forceinline__ void backward_body_gen(const P &p, int b0) {
     const T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
     const T *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
     const T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
-    T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
-    T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    T *kp = tile_ptr_v<GainLayout<M>::Vk>(p.k, tile, T1 * NU, ln);
+    T *Kp = tile_ptr_v<GainLayout<M>::VK>(p.K, tile, T1 * NU * NX, ln);
     // (the padding lanes of the last tile go with the regenerating sweep: whatever they compute stays in the padding)
     const bool regen = !valid || (p.slow_trig[o] & SLOW_TRIG_REGEN) != 0;
     const bool whole = valid && !regen;
@@ -1740,25 +1739,46 @@ template <typename T> __global__ __launch_bounds__(64) void ltv12x4_backward_red
 
 // ---------------------------------------------------------------- rollout step
 // u_new = (u_prev + alpha k) + K (x_new - x_prev), clamped (ilqr.py:56-61).
-template <typename T, class M, class P>
+// The reference's clamp is two comparisons (`if u < lo: u = lo`, `if u > hi: u = hi`), which leave a
+// NaN as it is.  !FAST states exactly that, three instructions per bound and input on this chip
+// (compare, two 32-bit selects).  FAST takes the maximum and the minimum instead, one instruction
+// per bound, which agree with the comparisons for every ordered value but return the bound for a
+// NaN: an unordered input is reported in `bad` (one compare for a pair of inputs) and the caller
+// repeats its sweep with FAST = false, as for an angle outside the fast trigonometric range.
+template <bool FAST, typename T> __device__ __forceinline__ T fmax_(T a, T b);
+template <> __device__ __forceinline__ double fmax_<true, double>(double a, double b) { return __builtin_fmax(a, b); }
+template <> __device__ __forceinline__ float fmax_<true, float>(float a, float b) { return __builtin_fmaxf(a, b); }
+template <bool FAST, typename T> __device__ __forceinline__ T fmin_(T a, T b);
+template <> __device__ __forceinline__ double fmin_<true, double>(double a, double b) { return __builtin_fmin(a, b); }
+template <> __device__ __forceinline__ float fmin_<true, float>(float a, float b) { return __builtin_fminf(a, b); }
+template <bool FAST, typename T, class M, class P>
 __device__ __forceinline__ void control_update(const P &p, T alpha, const T (&x)[M::NX], const T (&xp)[M::NX], const T (&up)[M::NU],
-                                               const T (&Kt)[M::NU][M::NX], const T (&kt)[M::NU], T (&un)[M::NU]) {
+                                               const T (&Kt)[M::NU][M::NX], const T (&kt)[M::NU], T (&un)[M::NU], bool &bad) {
     constexpr int NX = M::NX, NU = M::NU;
     T dx[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) dx[i] = x[i] - xp[i];
+    T raw[NU];
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
         T fb = Kt[i][0] * dx[0];
 #pragma unroll
         for (int j = 1; j < NX; ++j) fb = fma_(Kt[i][j], dx[j], fb);
         T v = fma_(alpha, kt[i], up[i]) + fb;
-        // min(max(v, lo), hi) with Python's NaN behaviour (a NaN stays a NaN).  Without control
-        // limits the host passes lo = -inf, hi = +inf, which makes this the identity, so the time
-        // step has no branch.
-        v = (p.lo[i] > v) ? p.lo[i] : v;
-        v = (p.hi[i] < v) ? p.hi[i] : v;
+        raw[i] = v;
+        // Without control limits the host passes lo = -inf, hi = +inf, which makes the clamp the
+        // identity, so the time step has no branch.
+        if (FAST) {
+            v = fmin_<true, T>(fmax_<true, T>(v, p.lo[i]), p.hi[i]);
+        } else {
+            v = (p.lo[i] > v) ? p.lo[i] : v;
+            v = (p.hi[i] < v) ? p.hi[i] : v;
+        }
         un[i] = v;
+    }
+    if (FAST) {
+#pragma unroll
+        for (int i = 0; i < NU; i += 2) bad = bad || __builtin_isunordered(raw[i], raw[i + 1 < NU ? i + 1 : i]);
     }
 }
 
@@ -1775,7 +1795,7 @@ __device__ __forceinline__ void candidate_step(const P &p, int t, T alpha, const
     T e[NX], un[NU], xn[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) e[i] = x[i] - r.xr[i];
-    control_update<T, M>(p, alpha, x, r.xp, r.up, r.K, r.k, un);
+    control_update<FAST, T, M>(p, alpha, x, r.xp, r.up, r.K, r.k, un, bad);
     T stage = quad_<T, NX, DIAG>(p.Q, e) + quad_<T, NU, DIAG>(p.R, un);
     if (BARRIER && t > 0) {
         T dlx[NX], dlxx[NX][NX];
@@ -1825,10 +1845,10 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
     auto load_row = [&](int t, FwdRow<T, NX, NU> &r) {
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-            r.k[i] = kp[(t * NU + i) * TILE];
+            r.k[i] = kp[gain_k<M>(t, i)];
             r.up[i] = Ut[(t * NU + i) * TILE];
 #pragma unroll
-            for (int j = 0; j < NX; ++j) r.K[i][j] = Kp[((t * NU + i) * NX + j) * TILE];
+            for (int j = 0; j < NX; ++j) r.K[i][j] = Kp[gain_K<M>(t * NU + i, j)];
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -1910,10 +1930,22 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
                 }
             }
         } else {
-            for (int t = 0; t < T1; ++t) {
-                FwdRow<T, NX, NU> r = nxt;
-                if (t + 1 < T1) load_row(t + 1, nxt);
-                one_step(t, r);
+            // two steps per trip, the rows alternating between two register sets: a single set that is
+            // copied at the top of every step costs a move per value and step
+            FwdRow<T, NX, NU> nx2;
+            int t = 0;
+            for (; t + 2 < T1; t += 2) {
+                load_row(t + 1, nx2);
+                one_step(t, nxt);
+                load_row(t + 2, nxt);
+                one_step(t + 1, nx2);
+            }
+            if (t + 1 < T1) {
+                load_row(t + 1, nx2);
+                one_step(t, nxt);
+                one_step(t + 1, nx2);
+            } else if (t < T1) {
+                one_step(t, nxt);
             }
         }
         // terminal term (ilqr.py:44-45)
@@ -1985,8 +2017,8 @@ __device__ __forceinline__ void evaluate_body(const P &p, int end, int wave, int
     const T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
     const T *Cp = BARRIER ? tile_ptr(p.centers, tile, p.N * 2, ln) : nullptr;
     const T *Dp = BARRIER ? tile_ptr(p.radius, tile, p.N, ln) : nullptr;
-    const T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
-    const T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    const T *kp = tile_ptr_v<GainLayout<M>::Vk>(p.k, tile, T1 * NU, ln);
+    const T *Kp = tile_ptr_v<GainLayout<M>::VK>(p.K, tile, T1 * NU * NX, ln);
     int best;
     T best_cost;
     bool bad = false;
@@ -2074,14 +2106,15 @@ template <typename T, class M, bool BARRIER, int L, bool REROLL> struct ListedPi
     int al, N, T1;
     // rows [r0, r0 + n) of an array with `rows` rows per problem: lane al takes every L-th; past
     // either end the nearest valid row is fetched instead (no branch around a load)
-    template <class D> __device__ __forceinline__ void fetch(const T *src, int r0, int n, int rows, D &dst) const {
+    // (V: rows interleaved per problem in this array, see GainLayout)
+    template <int V = 1, class D> __device__ __forceinline__ void fetch(const T *src, int r0, int n, int rows, D &dst) const {
 #pragma unroll
         for (int i = 0; i < C::cnt(n); ++i) {
             int e = al + L * i;
             e = e < n ? e : n - 1;
             int r = r0 + e;
             r = r < rows ? r : rows - 1;
-            dst[i] = src[(size_t)r * TILE];
+            dst[i] = src[vrow<V>(r)];
         }
     }
     template <class D> __device__ __forceinline__ void put(int off, int n, const D &src) const {
@@ -2093,8 +2126,8 @@ template <typename T, class M, bool BARRIER, int L, bool REROLL> struct ListedPi
         }
     }
     __device__ __forceinline__ void fetch_block(int t0, Stage &st) const {
-        fetch(Kp, t0 * NU * NX, C::nK, T1 * NU * NX, st.K);
-        fetch(kp, t0 * NU, C::nk, T1 * NU, st.k);
+        fetch<GainLayout<M>::VK>(Kp, t0 * NU * NX, C::nK, T1 * NU * NX, st.K);
+        fetch<GainLayout<M>::Vk>(kp, t0 * NU, C::nk, T1 * NU, st.k);
         fetch(Ut, t0 * NU, C::nk, T1 * NU, st.U);
         if (!REROLL) fetch(Xt, t0 * NX, C::nX, N * NX, st.X);
         fetch(Rt, t0 * NX, C::nX, N * NX, st.R);
@@ -2243,7 +2276,7 @@ __device__ __forceinline__ void listed_commit(const P &p, const ListedPipe<T, M,
                 for (int i = 0; i < NX; ++i) r.xp[i] = xq[i];
             }
             T un[NU], xn[NX];
-            control_update<T, M>(p, alpha, x, r.xp, r.up, r.K, r.k, un);
+            control_update<FAST, T, M>(p, alpha, x, r.xp, r.up, r.K, r.k, un, bad);
             M::template step<FAST>(p, t, x, un, xn, bad);
 #pragma unroll
             for (int i = 0; i < NX; ++i) x[i] = xn[i];
@@ -2290,8 +2323,8 @@ __global__ __launch_bounds__(64) void evaluate_listed_kernel(Params<T, M::NX, M:
     pipe.Ut = tile_ptr(p.U, tile, T1 * NU, ln);
     pipe.Cp = BARRIER ? tile_ptr(p.centers, tile, p.N * 2, ln) : nullptr;
     pipe.Dp = BARRIER ? tile_ptr(p.radius, tile, p.N, ln) : nullptr;
-    pipe.kp = tile_ptr(p.k, tile, T1 * NU, ln);
-    pipe.Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    pipe.kp = tile_ptr_v<GainLayout<M>::Vk>(p.k, tile, T1 * NU, ln);
+    pipe.Kp = tile_ptr_v<GainLayout<M>::VK>(p.K, tile, T1 * NU * NX, ln);
     pipe.lds = rows + pl * C::STRIDE;
     pipe.al = al;
     pipe.N = p.N;
@@ -2559,10 +2592,10 @@ __device__ __forceinline__ void commit_sweep(const P &p, T *Xt, T *Ut, const T *
     auto load_row = [&](int t, Row &r) {
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-            r.k[i] = kp[(t * NU + i) * TILE];
+            r.k[i] = kp[gain_k<M>(t, i)];
             r.up[i] = Ut[(t * NU + i) * TILE];
 #pragma unroll
-            for (int j = 0; j < NX; ++j) r.K[i][j] = Kp[((t * NU + i) * NX + j) * TILE];
+            for (int j = 0; j < NX; ++j) r.K[i][j] = Kp[gain_K<M>(t * NU + i, j)];
         }
         if (!REROLL) {
 #pragma unroll
@@ -2605,7 +2638,7 @@ __device__ __forceinline__ void commit_sweep(const P &p, T *Xt, T *Ut, const T *
                 for (int i = 0; i < NX; ++i) r.xp[i] = xq[i];
             }
             T un[NU], xn[NX], sn = T(0), cn = T(0);
-            control_update<T, M>(p, alpha, x, r.xp, r.up, r.K, r.k, un);
+            control_update<FAST, T, M>(p, alpha, x, r.xp, r.up, r.K, r.k, un, bad);
             model_step<FAST, false, M>(p, t, x, un, xn, sn, cn, bad);
 #pragma unroll
             for (int i = 0; i < NX; ++i) x[i] = xn[i];
@@ -2663,8 +2696,8 @@ __global__ __launch_bounds__(64) void commit_kernel(Params<T, M::NX, M::NU> p, i
     const int tile = b0 >> 6, ln = b0 & 63; // buffers are padded to whole tiles
     T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
     T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
-    const T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
-    const T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    const T *kp = tile_ptr_v<GainLayout<M>::Vk>(p.k, tile, T1 * NU, ln);
+    const T *Kp = tile_ptr_v<GainLayout<M>::VK>(p.K, tile, T1 * NU * NX, ln);
     T *trash = p.trash + b0;
     const int idx = p.alpha_idx[b];
     const bool pend = active && idx == -2; // listed for the second line-search stage, which also commits it
@@ -2869,14 +2902,15 @@ __device__ __forceinline__ void commit_segment_sweep(const P &p, T *Xt, T *Ut, c
         // one row pointer per array and compile-time offsets from it: the time index may differ from
         // lane to lane (solve_owned_kernel), and an index expression per value would then take an
         // address register pair per load
+        // (a time step's rows are a whole number of interleaved groups: NU % Vk == 0, NX % VK == 0)
         const T *kr = kp + (size_t)t * (NU * TILE), *ur = Ut + (size_t)t * (NU * TILE);
         const T *Kr = Kp + (size_t)t * (NU * NX * TILE), *xr = Xt + (size_t)t * (NX * TILE);
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-            r.k[i] = kr[i * TILE];
+            r.k[i] = kr[gain_k<M>(0, i)];
             r.up[i] = ur[i * TILE];
 #pragma unroll
-            for (int j = 0; j < NX; ++j) r.K[i][j] = Kr[(i * NX + j) * TILE];
+            for (int j = 0; j < NX; ++j) r.K[i][j] = Kr[gain_K<M>(i, j)];
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) r.xp[i] = xr[i * TILE];
@@ -2899,7 +2933,7 @@ __device__ __forceinline__ void commit_segment_sweep(const P &p, T *Xt, T *Ut, c
         Row r = ring[qr];
         load_row(t + RING, ring[qr]); // row t+RING is read before step t+RING-1 stores to it
         T un[NU], xn[NX], sn = T(0), cn = T(0);
-        control_update<T, M>(p, alpha, x, r.xp, r.up, r.K, r.k, un);
+        control_update<FAST, T, M>(p, alpha, x, r.xp, r.up, r.K, r.k, un, bad);
         model_step<FAST, false, M>(p, t, x, un, xn, sn, cn, bad);
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = xn[i];
@@ -2960,8 +2994,8 @@ __device__ __forceinline__ void commit_segments_body(const P &p, int it, int nse
     if (__ballot(roll) == 0ull) return;
     T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
     T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
-    const T *kp = tile_ptr(p.k, tile, T1 * NU, ln);
-    const T *Kp = tile_ptr(p.K, tile, T1 * NU * NX, ln);
+    const T *kp = tile_ptr_v<GainLayout<M>::Vk>(p.k, tile, T1 * NU, ln);
+    const T *Kp = tile_ptr_v<GainLayout<M>::VK>(p.K, tile, T1 * NU * NX, ln);
     T *SCt = TC ? tile_ptr(p.SC, tile, T1 * 2, ln) : nullptr;
     const T *CKp = tile_ptr(p.CK, tile, nseg * CK_CANDIDATES * NX, ln);
     const int t0 = seg * COMMIT_SEG, t1 = t0 + COMMIT_SEG < T1 ? t0 + COMMIT_SEG : T1;
@@ -3104,16 +3138,22 @@ static __global__ __launch_bounds__(1024) void repack_scan_kernel(const int32_t 
 
 template <typename T> struct RepackArray {
     const T *src;   // current working set, slot order
-    T *dst_active;  // next working set, slot order (null: array is not carried over)
-    T *dst_retire;  // caller's buffer, problem order (null: the data is already in place there)
+    const T *src_prev; // the working set before it (repack_retire_kernel, RepackArgs::gen_prev)
+    T *dst_active;  // next working set, slot order (repack_move_kernel)
+    T *dst_retire;  // caller's buffer, problem order (repack_retire_kernel)
     int rows;       // values per problem
     int chunk0;     // first chunk (REPACK_CHUNK rows each) of this array in the grid's y range
+    int vshift;     // log2 of the rows interleaved per problem (GainLayout; 0: plain tiled layout)
 };
+// offset of row i of lane `lane` from the start of a tile, V = 1 << vshift rows interleaved
+__device__ __forceinline__ size_t tile_elem(int i, int lane, int vshift) {
+    return (((size_t)(i >> vshift) * TILE + (size_t)lane) << vshift) + (size_t)(i & ((1 << vshift) - 1));
+}
 constexpr int REPACK_CHUNK = 32;
-// what happens to the problems of the current working set
-constexpr int REPACK_CARRY = 0;       // active: carried over to the next working set; converged: retired
-constexpr int REPACK_RETIRE_ALL = 1;  // every problem is retired (end of the solve)
-constexpr int REPACK_RETIRE_LIVE = 2; // only the problems that never converged are retired (end of the solve: their gains)
+// which problems of the current working set repack_retire_kernel copies back to the caller's buffers
+constexpr int REPACK_CARRY = 0;       // none (the active ones are being carried over to the next working set, the converged ones stay where they are)
+constexpr int REPACK_RETIRE_ALL = 1;  // every one (end of the solve)
+constexpr int REPACK_RETIRE_LIVE = 2; // the ones that never converged (end of the solve: their gains)
 template <typename T> struct RepackArgs {
     RepackArray<T> arr[7];
     int narr;
@@ -3125,13 +3165,22 @@ template <typename T> struct RepackArgs {
     int B;                        // problems of this part (slots before the first repack)
     int first;                    // global index of the part's first problem
     int mode;                     // REPACK_*
-    int32_t *carried;             // per problem: has been copied into a working set (its gains are not in the caller's buffers)
+    // per problem: the generation (1, 2, ..) of the last working set it was copied into, 0 = never (its
+    // trajectory and gains are in the caller's buffers); and its slot there
+    int32_t *carried;
+    int32_t *orig2slot;
+    int gen;                      // move: generation of the working set being built; retire: of the current one
+    // retire: the generation before the current one, or 0.  The problems that stayed behind in its working
+    // set (they converged while it was the current one) leave together with this launch's: a working set
+    // is only read out when the next but one is about to be built over it, or at the end of the solve
+    int gen_prev;
     int first_repack;             // the current arrays are the caller's buffers: define `carried` for every problem
 };
 
-// blockIdx.x: tile of the current working set; blockIdx.y: a chunk of REPACK_CHUNK rows of one of
-// the arrays.  Every wave moves its chunk for the 64 problems of the tile with all its loads in
-// flight together, so the copy runs at memory speed.
+// Source-major half of a repack: the active problems of the current working set go, in order, into
+// dense tiles of the next one.  blockIdx.x: tile of the current working set; blockIdx.y: a chunk of
+// REPACK_CHUNK rows of one of the arrays.  Every wave moves its chunk for the active problems of the
+// tile with all its loads in flight together; a wave's stores are one contiguous run per row.
 template <typename T> __global__ __launch_bounds__(64) void repack_move_kernel(RepackArgs<T> a) {
     const int tile = blockIdx.x, lane = threadIdx.x;
     const int s = tile * 64 + lane;
@@ -3139,21 +3188,22 @@ template <typename T> __global__ __launch_bounds__(64) void repack_move_kernel(R
     if (tile * 64 >= nsl) return;
     const bool valid = s < nsl;
     const int o = valid ? (a.slot2orig_old ? a.slot2orig_old[s] : s + a.first) : 0;
-    const bool live = valid && a.converged[o] == 0;
-    const bool act = live && a.mode == REPACK_CARRY;
-    const bool ret = valid && (a.mode == REPACK_RETIRE_ALL || (a.mode == REPACK_CARRY && !live) || (a.mode == REPACK_RETIRE_LIVE && live));
+    const bool act = valid && a.converged[o] == 0;
     const unsigned long long m = __ballot(act);
     const int ns = act ? a.tile_offset[tile] + (int)__popcll(m & ((1ull << lane) - 1ull)) : 0;
-    if (act && blockIdx.y == 0) a.slot2orig_new[ns] = o;
-    if (valid && blockIdx.y == 0 && a.mode == REPACK_CARRY && (act || a.first_repack)) a.carried[o] = act ? 1 : 0;
+    if (blockIdx.y == 0) {
+        if (act) {
+            a.slot2orig_new[ns] = o;
+            a.orig2slot[o] = ns;
+        }
+        if (valid && (act || a.first_repack)) a.carried[o] = act ? a.gen : 0;
+    }
+    if (m == 0ull) return;
     int q = 0;
     while (q + 1 < a.narr && (int)blockIdx.y >= a.arr[q + 1].chunk0) ++q;
     const RepackArray<T> r = a.arr[q];
     const int i0 = ((int)blockIdx.y - r.chunk0) * REPACK_CHUNK;
-    T *dst = (act && r.dst_active) ? r.dst_active + (size_t)(ns >> 6) * r.rows * TILE + (ns & 63)
-             : (ret && r.dst_retire) ? r.dst_retire + (size_t)(o >> 6) * r.rows * TILE + (o & 63)
-                                     : nullptr;
-    if (__ballot(dst != nullptr) == 0ull) return;
+    T *dst = act ? r.dst_active + (size_t)(ns >> 6) * r.rows * TILE + (ns & 63) : nullptr;
     const T *src = r.src + (size_t)tile * r.rows * TILE + lane;
     T v[REPACK_CHUNK];
 #pragma unroll
@@ -3166,6 +3216,46 @@ template <typename T> __global__ __launch_bounds__(64) void repack_move_kernel(R
         for (int j = 0; j < REPACK_CHUNK; ++j)
             if (i0 + j < r.rows) dst[(size_t)(i0 + j) * TILE] = v[j];
     }
+}
+
+// Destination-major half: problems of the current working set go back to their place in the caller's
+// buffers.  A problem's values there are 8 bytes of a line it shares with 15 neighbours that leave at
+// other times (or never entered a working set), and lines written in pieces reach memory at a fraction
+// of the streaming rate.  So a wave owns a tile of the CALLER's buffer x a chunk of rows: every lane
+// reads its row value either from its problem's slot in the working set (problems that leave now; a
+// tile's problems sit in the working set in order, within one or two of its tiles) or from the
+// caller's buffer itself (everybody else), and whole lines are written back; the lines of a row in
+// which nobody leaves are skipped.  blockIdx.x: tile of the part in the caller's buffers.
+template <typename T> __global__ __launch_bounds__(64) void repack_retire_kernel(RepackArgs<T> a) {
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    const int ol = tile * 64 + lane;
+    const bool valid = ol < a.B;
+    const int o = a.first + (valid ? ol : a.B - 1);
+    const bool live = a.converged[o] == 0;
+    const int g = valid ? a.carried[o] : 0;
+    const bool prev = a.gen_prev > 0 && g == a.gen_prev;
+    const bool ret = prev || (g > 0 && g == a.gen && (a.mode == REPACK_RETIRE_ALL || (a.mode == REPACK_RETIRE_LIVE && live)));
+    const unsigned long long m = __ballot(ret);
+    if (m == 0ull) return;
+    const bool line_on = ((m >> (lane & 48)) & 0xffffull) != 0ull; // somebody of this lane's line leaves
+    const int slot = ret ? a.orig2slot[o] : 0;
+    int q = 0;
+    while (q + 1 < a.narr && (int)blockIdx.y >= a.arr[q + 1].chunk0) ++q;
+    const RepackArray<T> r = a.arr[q];
+    const int i0 = ((int)blockIdx.y - r.chunk0) * REPACK_CHUNK;
+    T *dst = r.dst_retire + (size_t)((a.first >> 6) + tile) * r.rows * TILE;
+    const T *src = ret ? (prev ? r.src_prev : r.src) + (size_t)(slot >> 6) * r.rows * TILE : dst;
+    const int sl = ret ? (slot & 63) : lane;
+    if (!line_on) return;
+    T v[REPACK_CHUNK];
+#pragma unroll
+    for (int j = 0; j < REPACK_CHUNK; ++j) {
+        const int i = i0 + j < r.rows ? i0 + j : r.rows - 1; // no branch around the loads
+        v[j] = src[tile_elem(i, sl, r.vshift)];
+    }
+#pragma unroll
+    for (int j = 0; j < REPACK_CHUNK; ++j)
+        if (i0 + j < r.rows) dst[tile_elem(i0 + j, lane, r.vshift)] = v[j];
 }
 
 // ---------------------------------------------------------------- model probe
@@ -3255,8 +3345,9 @@ __global__ __launch_bounds__(64) void shift_kernel(T *X, T *U, int32_t *converge
 // reference layout [B][rows] (one problem contiguous) <-> tiled device layout
 // [ceil(B/64)][rows][64].  One workgroup moves a 64-problem x 64-row patch through LDS so
 // both the global read and the global write are contiguous.
+// vshift: log2 of the rows interleaved per problem on the tiled side (0: plain; see GainLayout)
 template <typename E, bool TO_TILED>
-__global__ __launch_bounds__(256) void relayout_kernel(const E *__restrict__ src, E *__restrict__ dst, int B, int rows) {
+__global__ __launch_bounds__(256) void relayout_kernel(const E *__restrict__ src, E *__restrict__ dst, int B, int rows, int vshift) {
     __shared__ E patch[64][65];
     const int tile = blockIdx.y, r0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -3269,12 +3360,12 @@ __global__ __launch_bounds__(256) void relayout_kernel(const E *__restrict__ src
         __syncthreads();
         for (int i = ty; i < 64; i += 4) { // row r0 + i, lane tx
             const int r = r0 + i;
-            if (r < rows) dst[tbase + (size_t)r * TILE + tx] = patch[tx][i];
+            if (r < rows) dst[tbase + tile_elem(r, tx, vshift)] = patch[tx][i];
         }
     } else {
         for (int i = ty; i < 64; i += 4) {
             const int r = r0 + i;
-            if (r < rows) patch[i][tx] = src[tbase + (size_t)r * TILE + tx];
+            if (r < rows) patch[i][tx] = src[tbase + tile_elem(r, tx, vshift)];
         }
         __syncthreads();
         for (int i = ty; i < 64; i += 4) {

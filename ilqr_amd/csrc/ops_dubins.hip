@@ -1,5 +1,14 @@
-// Kernel instantiations for the Dubins dynamics (fp64 and fp32, diagonal and dense cost weights).
+// Launch tables of the dubins dynamics (fp64 and fp32, diagonal and dense cost weights); the kernels
+// themselves are instantiated by ops_variant.hip, one translation unit per combination.
 #include "host.hpp"
 namespace ilqr {
-const ModelOps *ops_dubins(int dtype, bool diag) { return ops_for<DubinsModel>(dtype, diag); }
+const ModelOps *ops_dubins_f64_diag();
+const ModelOps *ops_dubins_f64_dense();
+const ModelOps *ops_dubins_f32_diag();
+const ModelOps *ops_dubins_f32_dense();
+const ModelOps *ops_dubins(int dtype, bool diag) {
+    if (dtype == ILQR_F64) return diag ? ops_dubins_f64_diag() : ops_dubins_f64_dense();
+    if (dtype == ILQR_F32) return diag ? ops_dubins_f32_diag() : ops_dubins_f32_dense();
+    return nullptr;
+}
 } // namespace ilqr

@@ -1,15 +1,11 @@
 """Seeded problem constructions for the batched iLQR path.
 
-Two families:
-
-* ``demo_*``: the three problem constructions of the reference demos
-  (``ilqr_demo.py:9-49`` Car, ``:89-135`` CarAcceleration, ``:170-192``
-  DubinsCar and ``cilqr.py:154-196``), with the module-level ``random`` stream
-  seeded explicitly so they are reproducible.
-* ``car_batch`` / ``caracc_batch`` / ``dubins_batch``: the batched synthetic
-  generator.  Problem ``b`` draws everything from
-  ``numpy.random.Generator(PCG64(seed0 + b))`` so its data do not depend on the
-  batch size or on how the batch is sharded over GPUs.
+``car_batch`` / ``caracc_batch`` / ``dubins_batch`` / ``ltv_batch`` / ``sqp_batch`` ...: the batched
+synthetic generators.  Problem ``b`` draws everything from
+``numpy.random.Generator(PCG64(seed0 + b))`` so its data do not depend on the
+batch size or on how the batch is sharded over GPUs.  (The seeded restatements of the reference
+demos' own problem constructions, which the golden fixtures are made from, are test
+infrastructure: ``oracle/demo_problems.py``.)
 
 Everything here is host-side numpy in the reference's array layout
 (``target_states (B, N, n)``, ``inputs (B, N-1, m)``, ``x0 (B, n)``).
@@ -27,83 +23,6 @@ CARACC_LIMITS = ([-6.0, -0.2], [6.0, 0.2])
 DUBINS_Q = 100.0 * np.diag([1.0, 1.0, 1.0])
 DUBINS_R = np.diag([10.0, 100.0])
 DUBINS_LIMITS = ([0.0, -0.2], [2.0, 0.2])
-
-
-def demo_car(horizon=120, seed=0, noise_xy=3.0, noise_th=0.5):
-    """Problem of ``ilqr_demo.py:10-45`` (noise_xy=3) or ``cilqr.py:155-192``
-    (noise_xy=15) with ``random.seed(seed)``.  Returns (noisy_targets,
-    init_inputs, ref_vel)."""
-    rnd = _pyrandom.Random(seed)
-    target = np.zeros((horizon, 4))
-    noisy = np.zeros((horizon, 4))
-    ref_vel = np.zeros(horizon)
-    dt, curv, a, v_max = 0.2, 0.1, 1.5, 11
-    for i in range(40, horizon):
-        if ref_vel[i - 1] > v_max:
-            a = 0
-        ref_vel[i] = ref_vel[i - 1] + a * dt
-    for i in range(1, horizon):
-        target[i, 0] = target[i - 1, 0] + np.cos(target[i - 1, 3]) * dt * ref_vel[i - 1]
-        target[i, 1] = target[i - 1, 1] + np.sin(target[i - 1, 3]) * dt * ref_vel[i - 1]
-        target[i, 2] = ref_vel[i]
-        target[i, 3] = target[i - 1, 3] + curv * dt
-        noisy[i, 0] = target[i, 0] + rnd.uniform(0, noise_xy)
-        noisy[i, 1] = target[i, 1] + rnd.uniform(0, noise_xy)
-        noisy[i, 2] = ref_vel[i]
-        noisy[i, 3] = target[i, 3] + rnd.uniform(0, noise_th)
-    init_inputs = np.zeros((horizon - 1, 2))
-    for i in range(1, horizon):
-        init_inputs[i - 1, 0] = (noisy[i, 2] - noisy[i - 1, 2]) / dt
-        init_inputs[i - 1, 1] = (noisy[i, 3] - noisy[i - 1, 3]) / dt
-    return noisy, init_inputs, ref_vel
-
-
-def demo_caracc(horizon=100, seed=0):
-    """Problem of ``ilqr_demo.py:89-131`` with ``random.seed(seed)``."""
-    rnd = _pyrandom.Random(seed)
-    target = np.zeros((horizon, 5))
-    noisy = np.zeros((horizon, 5))
-    ref_vel = np.zeros(horizon)
-    ref_acc = np.zeros(horizon)
-    dt, curv, a, v_max = 0.2, 0.1, 1.5, 11
-    for i in range(40, horizon):
-        if ref_vel[i - 1] > v_max:
-            a = 0
-        ref_acc[i] = a
-        ref_vel[i] = ref_vel[i - 1] + a * dt
-    for i in range(1, horizon):
-        target[i, 0] = target[i - 1, 0] + np.cos(target[i - 1, 4]) * dt * ref_vel[i - 1]
-        target[i, 1] = target[i - 1, 1] + np.sin(target[i - 1, 4]) * dt * ref_vel[i - 1]
-        target[i, 2] = ref_vel[i]
-        target[i, 3] = ref_acc[i]
-        target[i, 4] = target[i - 1, 4] + curv * dt
-        noisy[i, 0] = target[i, 0] + rnd.uniform(0, 1)
-        noisy[i, 1] = target[i, 1] + rnd.uniform(0, 1)
-        noisy[i, 2] = target[i, 2]
-        noisy[i, 3] = target[i, 3]
-        noisy[i, 4] = target[i, 4] + rnd.uniform(0, 0.1)
-    init_inputs = np.zeros((horizon - 1, 2))
-    for i in range(1, horizon):
-        init_inputs[i - 1, 0] = (noisy[i, 3] - noisy[i - 1, 3]) / dt
-        init_inputs[i - 1, 1] = (noisy[i, 4] - noisy[i - 1, 4]) / dt
-    return noisy, init_inputs
-
-
-def demo_dubins(horizon=200, seed=0):
-    """Problem of ``ilqr_demo.py:170-185`` with ``random.seed(seed)``; the demo
-    leaves the inputs at zero."""
-    rnd = _pyrandom.Random(seed)
-    target = np.zeros((horizon, 3))
-    noisy = np.zeros((horizon, 3))
-    dt, v, curv = 0.2, 1.0, 0.1
-    for i in range(1, horizon):
-        target[i, 0] = target[i - 1, 0] + np.cos(target[i - 1, 2]) * v * dt
-        target[i, 1] = target[i - 1, 1] + np.sin(target[i - 1, 2]) * v * dt
-        target[i, 2] = target[i - 1, 2] + v * curv * dt
-        noisy[i, 0] = target[i, 0] + rnd.uniform(0, 1)
-        noisy[i, 1] = target[i, 1] + rnd.uniform(0, 1)
-        noisy[i, 2] = target[i, 2] + rnd.uniform(0, 1)
-    return noisy, np.zeros((horizon - 1, 2))
 
 
 def _one_car(b, seed0, N, dt, noise_xy, noise_th, ramp_start):
@@ -337,8 +256,8 @@ SQP_R = np.diag([300.0, 1000.0])
 SQP_LIMITS = ([-1.0, -0.3], [1.0, 0.3])
 
 
-def demo_sqp(horizon=80, seed=0, noisy=0.5, curv=0.1, radius=0.6):
-    """Problem of ``sqp_demo.py:12-53`` (``random_example``) with ``random.seed(seed)``: unit-speed arc,
+def sqp_arc_problem(horizon=80, seed=0, noisy=0.5, curv=0.1, radius=0.6):
+    """One problem shaped like ``sqp_demo.py:12-53`` (``random_example``), seeded: unit-speed arc,
     noisy targets, bubbles of the given radius centred on the noisy targets, speed bounds [0, 2].
     Returns (noisy_targets, init_inputs, centers, radius, vel_bounds)."""
     rnd = _pyrandom.Random(seed)
@@ -374,7 +293,7 @@ def sqp_batch(B, N=80, seed0=2468, first=0):
     radius = np.zeros((B, N))
     for b in range(B):
         rng = np.random.Generator(np.random.PCG64(seed0 + first + b))
-        t, u, c, r, vb = demo_sqp(N, seed=int(rng.integers(1 << 30)), noisy=rng.uniform(0.2, 0.6),
+        t, u, c, r, vb = sqp_arc_problem(N, seed=int(rng.integers(1 << 30)), noisy=rng.uniform(0.2, 0.6),
                                   curv=rng.uniform(-0.2, 0.2), radius=rng.uniform(0.5, 0.9))
         tg[b], ui[b], centers[b], radius[b] = t, u, c, r
     return dict(target_states=tg, init_inputs=ui, centers=centers, radius=radius, vel_bounds=(0.0, 2.0))

@@ -18,6 +18,10 @@
  *   Xref   rows = N*n        target_states     (ilqr.py:18)
  *   K      rows = (N-1)*m*n  feedback gains    (ilqr.py:78  self.K)
  *   k      rows = (N-1)*m    feed-forward      (ilqr.py:77  self.k)
+ *          The two gain arrays interleave V consecutive rows of a problem (ilqr_gain_layout; V = 1,
+ *          2 or 4): [ceil(B/64)][rows/V][64][V], element (b, r) at
+ *          ((b/64)*(rows/V) + r/V)*64*V + (b%64)*V + r%V.  Convert with ilqr_to_tiled_v /
+ *          ilqr_from_tiled_v.  V = 1 is the plain layout above.
  *   centers rows = N*2, radius rows = N        (constraints.py:15-18, per problem)
  * Per-problem scalars are plain arrays of B elements:
  *   J      [B]            min_cost          (ilqr.py:29)
@@ -171,6 +175,11 @@ int32_t ilqr_num_alphas(const ilqr_handle *h);
 /* the forward mapping in use (the descriptor's, or the one chosen for 0 = auto): the first stage
  * of the line search rolls out lanes_per_problem * alphas_per_lane step sizes per problem */
 int ilqr_forward_mapping(const ilqr_handle *h, int32_t *lanes_per_problem, int32_t *alphas_per_lane);
+/* the effective sparse-states setting (the descriptor's recompute_states after the exclusions with
+ * the sine/cosine cache, the time-parallel commit and the constraint modes): 0 = commits store every
+ * state row, 1 = every 8th row inside ilqr_solve only, 2 = also between the phase calls (the caller
+ * asks for X with ilqr_states).  No reference counterpart (ilqr.py keeps `states` whole). */
+int32_t ilqr_sparse_states(const ilqr_handle *h);
 
 /* attaches device buffers; replaces the attribute assignments of ilqr_demo.py:47-49 */
 int ilqr_bind(ilqr_handle *h, const ilqr_buffers *bufs);
@@ -310,6 +319,13 @@ void *ilqr_sqp_solved_inputs(const ilqr_handle *h, void *work);
  * pointers are device pointers; padding lanes of the last tile are zero-filled */
 int ilqr_to_tiled(const void *aos, void *tiled, int32_t B, int32_t rows, int32_t elem_bytes, void *stream);
 int ilqr_from_tiled(const void *tiled, void *aos, int32_t B, int32_t rows, int32_t elem_bytes, void *stream);
+/* the same for an array that interleaves `vec` (1, 2 or 4; rows % vec == 0) consecutive rows per problem
+ * on the tiled side: the gain buffers K and k.  The reference holds the gains as plain arrays
+ * (ilqr.py:77-78); these two calls and ilqr_gain_layout stand between that and the device layout. */
+int ilqr_to_tiled_v(const void *aos, void *tiled, int32_t B, int32_t rows, int32_t elem_bytes, int32_t vec, void *stream);
+int ilqr_from_tiled_v(const void *tiled, void *aos, int32_t B, int32_t rows, int32_t elem_bytes, int32_t vec, void *stream);
+/* rows interleaved per problem in this handle's K and k buffers (a function of n and m only) */
+int ilqr_gain_layout(const ilqr_handle *h, int32_t *vec_K, int32_t *vec_k);
 
 const char *ilqr_strerror(int code);
 /* hipError_t of the last failing HIP call on this thread (0 if none) */

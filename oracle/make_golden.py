@@ -26,6 +26,7 @@ import ilqr as ref_ilqr  # noqa: E402  (the reference)
 import systems as ref_systems  # noqa: E402  (the reference)
 
 from ilqr_amd import problems  # noqa: E402
+from oracle import demo_problems  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 
@@ -293,18 +294,18 @@ def main():
         fn()
     # Car, the demo construction (ilqr_demo.py:9-49), N=200 x 3 seeds and the demo's N=120
     for N, seed in ((200, 0), (200, 1), (200, 2), (120, 0)):
-        tg, ui, _ = problems.demo_car(N, seed)
+        tg, ui, _ = demo_problems.demo_car(N, seed)
         car = make_car()
         save(f"car_N{N}_seed{seed}", car, tg, ui, None, run_reference(car, tg, ui))
     # CarAcceleration demo (ilqr_demo.py:89-135)
-    tg, ui = problems.demo_caracc(100, 0)
+    tg, ui = demo_problems.demo_caracc(100, 0)
     s = ref_systems.CarAcceleration()
     s.set_dt(0.2)
     s.set_cost(problems.CARACC_Q.copy(), problems.CARACC_R.copy())
     s.set_control_limit(*problems.CARACC_LIMITS)
     save("caracc_N100_seed0", s, tg, ui, None, run_reference(s, tg, ui))
     # DubinsCar demo (ilqr_demo.py:170-192), inputs start at zero
-    tg, ui = problems.demo_dubins(200, 0)
+    tg, ui = demo_problems.demo_dubins(200, 0)
     s = ref_systems.DubinsCar()
     s.set_dt(0.2)
     s.set_cost(problems.DUBINS_Q.copy(), problems.DUBINS_R.copy())
@@ -319,7 +320,7 @@ def main():
     save("car_N200_x0guess", car, p["target_states"][0], p["init_inputs"][0], p["x0"][0],
          run_reference(car, p["target_states"][0], p["init_inputs"][0],
                        init_states=p["init_states"][0]), init_states=p["init_states"][0])
-    tg, ui, _ = problems.demo_car(200, 3)
+    tg, ui, _ = demo_problems.demo_car(200, 3)
     car = make_car(limited=False)
     save("car_N200_nolimit", car, tg, ui, None, run_reference(car, tg, ui))
     user_models()

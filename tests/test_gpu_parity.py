@@ -13,6 +13,7 @@ import pytest
 
 from conftest import (demo_car_system, golden_names, load_golden, noise_floor_mask,
                       system_from_golden)
+from oracle import demo_problems
 
 pytestmark = pytest.mark.gpu
 
@@ -347,7 +348,7 @@ def test_dense_weights_and_lm_parameter(ilqr_cls, oracle):
     car.set_cost(Q, Rm)
     car.set_final_cost(Q * 30)
     car.set_control_limit([-1.5, -0.3], [1.5, 0.3])
-    tg, ui, _ = problems.demo_car(80, 2)
+    tg, ui, _ = demo_problems.demo_car(80, 2)
     for lm in (0.0, 5.0):
         opt = ilqr_cls(car, tg, car.dt, history=True)
         opt.inputs, opt.LM_parameter, opt.maxIter = ui.copy(), lm, 8
@@ -368,7 +369,7 @@ def test_indefinite_quu_takes_lu_path_and_is_flagged(ilqr_cls, oracle):
     from ilqr_amd import _lib, problems, systems
     car = systems.Car()
     car.set_cost(np.diag([50.0, 50.0, 1000.0, 0.0]), np.diag([-50.0, 1000.0]))   # indefinite R
-    tg, ui, _ = problems.demo_car(30, 1)
+    tg, ui, _ = demo_problems.demo_car(30, 1)
     opt = ilqr_cls(car, tg, car.dt, history=True)
     opt.inputs, opt.maxIter = ui.copy(), 1
     opt()
@@ -398,7 +399,7 @@ def test_fp32_mode(ilqr_cls, oracle):
 def cilqr_problem(N=120, seed=0):
     """The construction of cilqr.py:154-196: noise U(0,15), Q_f = 2Q."""
     from ilqr_amd import problems, systems
-    tg, ui, _ = problems.demo_car(N, seed, noise_xy=15.0)
+    tg, ui, _ = demo_problems.demo_car(N, seed, noise_xy=15.0)
     car = systems.Car()
     car.set_dt(0.2)
     car.set_cost(problems.CAR_Q.copy(), problems.CAR_R.copy())
@@ -435,7 +436,7 @@ def test_cilqr_matches_oracle(oracle, seed):
 def test_cilqr_equals_ilqr_when_no_bound_is_active(ilqr_cls):
     from ilqr_amd import problems
     from ilqr_amd.cilqr import iterative_LQR as CILQR
-    tg, ui, _ = problems.demo_car(120, 5)
+    tg, ui, _ = demo_problems.demo_car(120, 5)
     car = demo_car_system(limited=False)
     car.set_control_limit([-1e6, -1e6], [1e6, 1e6])
     a = ilqr_cls(car, tg, car.dt, history=True)
@@ -1355,3 +1356,27 @@ def test_sparse_states_at_a_size_where_they_are_the_default(ilqr_cls):
     assert outs[0][4].any() and not outs[0][4].all()
     for i, (a, b) in enumerate(zip(*outs)):
         assert np.array_equal(a, b, equal_nan=True), i
+
+
+def test_history_of_a_second_call_with_fewer_iterations(ilqr_cls):
+    """maxIter may change between calls of one solver object (the device buffers stay): the histories
+    have maxIter columns and hold nothing of the earlier call."""
+    from ilqr_amd import problems
+    p = problems.car_batch(70, 60, first=11)
+    car = demo_car_system()
+    opt = ilqr_cls(car, p["target_states"], car.dt, history=True)
+    opt.inputs, opt.states = p["init_inputs"].copy(), p["init_states"].copy()
+    opt()
+    assert opt.cost_history.shape == (70, 30)
+    fresh = ilqr_cls(car, p["target_states"], car.dt, history=True)
+    fresh.maxIter = 5
+    fresh.inputs, fresh.states = p["init_inputs"].copy(), p["init_states"].copy()
+    fresh()
+    opt.maxIter = 5
+    opt.inputs, opt.states = p["init_inputs"].copy(), p["init_states"].copy()
+    opt.converge = np.zeros(70, dtype=bool)
+    opt()
+    assert opt.cost_history.shape == (70, 5) and opt.alpha_history.shape == (70, 5)
+    assert np.array_equal(opt.cost_history, fresh.cost_history, equal_nan=True)
+    assert np.array_equal(opt.alpha_history, fresh.alpha_history)
+    assert np.array_equal(opt.states, fresh.states) and np.array_equal(opt.iterations, fresh.iterations)

@@ -10,6 +10,7 @@ import pytest
 
 from conftest import noise_floor_mask
 from test_sqp_cpu import CASES, sqp_car
+from oracle import demo_problems
 
 pytestmark = pytest.mark.gpu
 
@@ -38,7 +39,7 @@ def test_single_problem_like_the_demo(oracle):
     """sqp_demo.py:12-58 with a seeded random stream, one problem, the reference's call sequence."""
     from oracle import sqp_oracle as so
     from ilqr_amd import problems
-    tg, ui, c, r, vb = problems.demo_sqp(80, 0)
+    tg, ui, c, r, vb = demo_problems.demo_sqp(80, 0)
     car = sqp_car(80)
     opt, con = _solver(car, c, r, vb, tg, ui)
     out = opt()
@@ -58,7 +59,7 @@ def test_first_qp_matches_both_oracle_solvers(seed, rad, vb, lim):
     from oracle import sqp_oracle as so
     from ilqr_amd import _lib, problems
     N = 60
-    tg, ui, c, r, _ = problems.demo_sqp(N, seed, radius=rad)
+    tg, ui, c, r, _ = demo_problems.demo_sqp(N, seed, radius=rad)
     car = sqp_car(N, lim)
     for fixed in (False, True):
         opt, con = _solver(car, c, r, vb, tg, ui)
@@ -142,7 +143,7 @@ def test_inputs_without_limits_and_iteration_budget():
     """control_limited = False: the QP has no input rows (sqp.py:38-39); maxIter is honoured."""
     from oracle import sqp_oracle as so
     from ilqr_amd import problems
-    tg, ui, c, r, vb = problems.demo_sqp(60, 4)
+    tg, ui, c, r, vb = demo_problems.demo_sqp(60, 4)
     car = sqp_car(60, limits=None)
     opt, con = _solver(car, c, r, vb, tg, ui)
     opt.maxIter = 2
@@ -158,7 +159,7 @@ def test_numpy_only_model_in_the_sequential_qp():
     from oracle import sqp_oracle as so
     from ilqr_amd import problems
     from ilqr_amd.user_models import NumpyCar
-    tg, ui, c, r, vb = problems.demo_sqp(70, 6)
+    tg, ui, c, r, vb = demo_problems.demo_sqp(70, 6)
     car = NumpyCar()
     car.set_cost(problems.SQP_Q.copy(), problems.SQP_R.copy())
     car.Q_f = car.Q * 70 / 100
@@ -178,7 +179,7 @@ def test_whole_solves_with_active_rows(seed, rad, vb, lim, fixed):
     from oracle import sqp_oracle as so
     from ilqr_amd import problems
     N = 60
-    tg, ui, c, r, _ = problems.demo_sqp(N, seed, radius=rad)
+    tg, ui, c, r, _ = demo_problems.demo_sqp(N, seed, radius=rad)
     car = sqp_car(N, lim)
     opt, con = _solver(car, c, r, vb, tg, ui)
     opt.init_input_fixed = fixed
@@ -200,7 +201,7 @@ def test_assigned_x0_umin_umax_are_honoured():
     from oracle import sqp_oracle as so
     from ilqr_amd import problems
     N = 60
-    tg, ui, c, r, vb = problems.demo_sqp(N, 4)
+    tg, ui, c, r, vb = demo_problems.demo_sqp(N, 4)
     car = sqp_car(N)
     x0 = tg[0] + np.array([0.02, -0.03, 0.1, 0.02])
     umin, umax = np.array([-0.02, -np.inf]), np.array([0.015, 0.1])      # three of the four rows get active

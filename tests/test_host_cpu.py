@@ -10,6 +10,7 @@ import pytest
 
 from conftest import ROOT, demo_car_system
 from ilqr_amd import _lib, problems, systems
+from oracle import demo_problems
 from ilqr_amd.constraints import BubbleConstraint
 
 
@@ -181,7 +182,7 @@ def test_problem_generator_is_shard_invariant():
     assert a["init_states"].shape == (8, 60, 4)
     assert np.array_equal(a["init_states"][:, 0], a["x0"])
     # demo construction is deterministic per seed and matches the stored fixture inputs
-    tg, ui, _ = problems.demo_car(200, 0)
+    tg, ui, _ = demo_problems.demo_car(200, 0)
     g = np.load(os.path.join(ROOT, "tests", "golden", "car_N200_seed0.npz"))
     assert np.array_equal(tg, g["target_states"]) and np.array_equal(ui, g["init_inputs"])
 
@@ -207,7 +208,7 @@ def test_solver_refuses_to_run_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
     from ilqr_amd.ilqr import iterative_LQR
-    tg, ui, _ = problems.demo_car(20, 0)
+    tg, ui, _ = demo_problems.demo_car(20, 0)
     opt = iterative_LQR(demo_car_system(), tg, 0.2)
     opt.inputs = ui
     with pytest.raises(_lib.IlqrError):
@@ -217,7 +218,7 @@ def test_solver_refuses_to_run_without_gpu():
 def test_solver_attribute_surface():
     from ilqr_amd.cilqr import iterative_LQR as CILQR
     from ilqr_amd.ilqr import iterative_LQR
-    tg, ui, _ = problems.demo_car(20, 0)
+    tg, ui, _ = demo_problems.demo_car(20, 0)
     car = demo_car_system()
     o = iterative_LQR(car, tg, 0.2)
     assert (o.horizon, o.n_states, o.m_inputs, o.maxIter, o.LM_parameter, o.converge, o.min_cost) == \

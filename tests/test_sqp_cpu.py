@@ -10,6 +10,7 @@ import pytest
 from ilqr_amd import _lib, problems, systems
 from ilqr_amd.constraints import BubbleConstraint
 from oracle import sqp_oracle as so
+from oracle import demo_problems
 
 
 def sqp_car(N=80, limits=problems.SQP_LIMITS):
@@ -32,7 +33,7 @@ CASES = [  # seed, bubble radius, speed bounds, input limits: nothing active / s
 @pytest.mark.parametrize("seed,rad,vb,lim", CASES)
 def test_qp_solvers_agree_and_satisfy_optimality(seed, rad, vb, lim):
     N = 60
-    tg, ui, c, r, _ = problems.demo_sqp(N, seed, radius=rad)
+    tg, ui, c, r, _ = demo_problems.demo_sqp(N, seed, radius=rad)
     car = sqp_car(N, lim)
     con = BubbleConstraint(N)
     con.setup(c, r, vb)
@@ -69,7 +70,7 @@ def test_qp_solvers_agree_and_satisfy_optimality(seed, rad, vb, lim):
 
 def test_oracle_sqp_runs_the_loop_of_the_reference():
     N = 50
-    tg, ui, c, r, vb = problems.demo_sqp(N, 3)
+    tg, ui, c, r, vb = demo_problems.demo_sqp(N, 3)
     car = sqp_car(N)
     con = BubbleConstraint(N)
     con.setup(c, r, vb)
@@ -128,7 +129,7 @@ def test_python_class_surface_and_refusal_without_gpu():
     """Constructor, attributes and defaults of sqp.py:17-42 / :63-65; no CPU fallback."""
     import torch
     from ilqr_amd.sqp import sequential_QP_optimizer
-    tg, ui, c, r, vb = problems.demo_sqp(30, 0)
+    tg, ui, c, r, vb = demo_problems.demo_sqp(30, 0)
     car = sqp_car(30)
     con = BubbleConstraint(30)
     con.setup(c, r, vb)

@@ -11,7 +11,8 @@ from conftest import demo_car_system
 pytestmark = pytest.mark.gpu
 
 
-def _run(B, N, static, work_null=False, **kw):
+def _run(B, N, static, work_null=False, want_sparse=None, **kw):
+    import torch
     from ilqr_amd import problems
     from ilqr_amd.ilqr import iterative_LQR
     car = demo_car_system()
@@ -19,12 +20,21 @@ def _run(B, N, static, work_null=False, **kw):
     opt = iterative_LQR(car, p["target_states"], car.dt, history=True, repack_every=-1, **kw)
     opt.inputs, opt.states = p["init_inputs"].copy(), p["init_states"].copy()
     dev = opt.upload()
+    if want_sparse is not None:
+        assert dev.sparse_states() == want_sparse
     if work_null:       # a caller without a workspace of its own
         dev.buffers.work = None
         from ilqr_amd import _lib
         _lib.check(dev.lib.ilqr_bind(dev.handle, C.byref(dev.buffers)), "ilqr_bind")
     if static:
+        # the call allocates nothing: the device's free memory is the same before and after
+        # (the caching allocator of the carrier tensors is idle in between)
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
         dev.solve_static(opt.maxIter)
+        torch.cuda.synchronize()
+        free1 = torch.cuda.mem_get_info()[0]
+        opt.free_delta = free0 - free1
     else:
         dev.solve(opt.maxIter)
     opt.download()
@@ -34,17 +44,42 @@ def _run(B, N, static, work_null=False, **kw):
 def test_static_scratch_solve_equals_ilqr_solve_twice():
     import torch
     assert torch.cuda.is_available()
-    # (the second call is the smaller one; the third keeps sparse states, whose bookkeeping lives in the same scratch)
-    for B, N, kw in ((700, 90, dict()), (130, 50, dict(lanes_per_problem=1, alphas_per_lane=6)),
-                     (333, 70, dict(lanes_per_problem=2, alphas_per_lane=3, recompute_states=2))):
-        ref, Kr, kr = _run(B, N, static=False, **kw)
-        got, Kg, kg = _run(B, N, static=True, work_null=True, **kw)
+    # (the second call is the smaller one; the third keeps sparse states, whose bookkeeping lives in the
+    # same scratch: asked for by value, they win over the sine/cosine cache and the time-parallel commit
+    # a batch of this size would get by default, and the handle says so)
+    cases = ((700, 90, dict(), None), (130, 50, dict(lanes_per_problem=1, alphas_per_lane=6), None),
+             (333, 70, dict(lanes_per_problem=2, alphas_per_lane=3, recompute_states=2), 2))
+    for i, (B, N, kw, sparse) in enumerate(cases):
+        ref, Kr, kr = _run(B, N, static=False, want_sparse=sparse, **kw)
+        got, Kg, kg = _run(B, N, static=True, work_null=True, want_sparse=sparse, **kw)
         assert (ref.iterations > 2).any() and ref.converge.any()
         for key in ("states", "inputs", "min_cost", "iterations", "converge", "status"):
             assert np.array_equal(getattr(got, key), getattr(ref, key)), (B, key)
         assert np.array_equal(got.alpha_history, ref.alpha_history)
         assert np.array_equal(got.cost_history, ref.cost_history, equal_nan=True)
         assert np.array_equal(Kg, Kr) and np.array_equal(kg, kr)
+        if i > 0:   # (the very first call on a device looks the array's address up, which may load the code object)
+            assert got.free_delta == 0, got.free_delta
+
+
+def test_sparse_states_between_phase_calls_on_request():
+    """recompute_states = 2 at a batch size that would get the sine/cosine cache by default: the
+    phase calls leave X sparse (the calls that start from X refuse until ilqr_states has run)."""
+    from ilqr_amd import problems
+    from ilqr_amd.ilqr import iterative_LQR
+    car = demo_car_system()
+    p = problems.car_batch(333, 70, first=3)
+    opt = iterative_LQR(car, p["target_states"], car.dt, repack_every=-1, recompute_states=2)
+    opt.inputs, opt.states = p["init_inputs"].copy(), p["init_states"].copy()
+    dev = opt.upload()
+    assert dev.sparse_states() == 2
+    dev.initial_cost()
+    for it in range(3):
+        dev.backward()
+        dev.forward(it)
+    assert dev.lib.ilqr_initial_cost(dev.handle, dev.stream()) == -6
+    dev.fill_states()
+    assert dev.lib.ilqr_initial_cost(dev.handle, dev.stream()) == 0
 
 
 def test_static_scratch_rejects_what_it_cannot_hold():

@@ -7,7 +7,7 @@ import sys
 
 src = sys.argv[1]
 filt = sys.argv[2:] if len(sys.argv) > 2 else []
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950",
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "--offload-arch=gfx950",
        "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 name = None

@@ -15,9 +15,19 @@ bench.py uses.
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def source_stamp():
+    """git's blob hash of the kernel source the counters were taken from: bench.py quotes a profile
+    only while the file it was taken from is the one in the tree."""
+    data = open(os.path.join(ROOT, "ilqr_amd", "csrc", "kernels.hpp"), "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 NAMES = (("backward_kernel", "backward"), ("backward_gen_kernel", "backward"), ("states_kernel", "states"), ("repack_move_kernel", "repack"), ("evaluate_listed_kernel", "evaluate_rest"), ("evaluate_kernel", "evaluate_first"),
          ("commit_kernel", "commit"), ("cost_kernel", "cost"), ("relayout_kernel", "relayout"))
@@ -51,6 +61,7 @@ def main():
         w = [wr[key][i] for i in keep] if key in wr and len(wr[key]) == len(rd[key]) else wr.get(key, [0.0])
         res[key] = {"launches": len(r), "read_bytes_per_launch": sum(r) / len(r), "write_bytes_per_launch": sum(w) / len(w),
                     "bytes_per_launch": sum(r) / len(r) + sum(w) / len(w), "max_bytes_per_launch": max(r) + max(w)}
+    res["_source"] = {"kernels_hpp": source_stamp()}
     txt = json.dumps(res, indent=1)
     print(txt)
     if out:

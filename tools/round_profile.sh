@@ -16,4 +16,5 @@ done
 cd $root
 python3 tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write $out/hbm_traffic.json > /dev/null || exit 1
 python3 tools/pmc_summary.py $out/pmc_sq $out/pmc_flops $out/pmc_occ > $out/pmc_summary.txt || exit 1
+python3 tools/pmc_limits.py $out/pmc_sq $out/pmc_flops $out/kernel_limits.json > /dev/null || exit 1
 cat $out/bench.json
