@@ -88,6 +88,7 @@ _SIGNATURES = {
     "ilqr_to_tiled_v": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ilqr_from_tiled_v": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ilqr_gain_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "ilqr_target_layout": (C.c_int32, [C.c_void_p]),
     "ilqr_load_model": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
     "ilqr_model_dims": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ilqr_model_probe": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

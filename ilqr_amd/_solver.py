@@ -231,7 +231,11 @@ class DeviceProblem:
         torch = _torch()
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _upload(self, host, tiled, rows):
+    def target_layout(self):
+        """Rows interleaved per problem in the device buffer Xref."""
+        return int(self.lib.ilqr_target_layout(self.handle))
+
+    def _upload(self, host, tiled, rows, vec=1):
         """host: array-like (B, rows...) in the reference layout -> tiled device buffer."""
         torch = _torch()
         if isinstance(host, torch.Tensor):
@@ -241,8 +245,8 @@ class DeviceProblem:
             if not a.flags.writeable:   # (a view of a read-only array: torch wants to be able to write)
                 a = a.copy()
             src = torch.from_numpy(a).to(self.device)
-        _lib.check(self.lib.ilqr_to_tiled(src.data_ptr(), tiled.data_ptr(), self.B, rows,
-                                          self.np_dtype.itemsize, self.stream()), "ilqr_to_tiled")
+        _lib.check(self.lib.ilqr_to_tiled_v(src.data_ptr(), tiled.data_ptr(), self.B, rows,
+                                            self.np_dtype.itemsize, vec, self.stream()), "ilqr_to_tiled_v")
         # `src` must outlive the asynchronous kernel: both run on the current stream, and torch's
         # caching allocator only reuses the block for later work on that same stream.
 
@@ -263,7 +267,7 @@ class DeviceProblem:
     def upload(self, target_states, states, inputs, converged=None, centers=None, radius=None):
         N, n, m = self.N, self.n, self.m
         self.fill_states()   # (the library must not hold sparse states of its own when X is rewritten)
-        self._upload(target_states, self.Xref, N * n)
+        self._upload(target_states, self.Xref, N * n, vec=self.target_layout())
         self._upload(states, self.X, N * n)
         self._upload(inputs, self.U, (N - 1) * m)
         torch = _torch()

@@ -246,7 +246,7 @@ static hipError_t repack_launch(ilqr_handle *h, PartState &ps, int mode, hipStre
         a.gen = ps.gen + 1;
         add(Xc, set_ptr(q, 0, N * n), nullptr, N * n);
         add(Uc, set_ptr(q, 1, T1 * m), nullptr, T1 * m);
-        add(Rc, set_ptr(q, 2, N * n), nullptr, N * n);
+        add(Rc, set_ptr(q, 2, N * n), nullptr, N * n, barrier ? 1 : gain_vec_of(n, n)); // (TargetLayout)
         if (barrier) {
             add(Cc, set_ptr(q, 3, N * 2), nullptr, N * 2);
             add(Dc, set_ptr(q, 4, N), nullptr, N);
@@ -821,6 +821,11 @@ int ilqr_to_tiled_v(const void *aos, void *tiled, int32_t B, int32_t rows, int32
 
 int ilqr_from_tiled_v(const void *tiled, void *aos, int32_t B, int32_t rows, int32_t elem_bytes, int32_t vec, void *stream) {
     return relayout<false>(tiled, aos, B, rows, elem_bytes, vec, stream);
+}
+
+int32_t ilqr_target_layout(const ilqr_handle *h) {
+    if (!h) return 0;
+    return (h->ctx.d.constraint_mode & ILQR_CONSTR_BARRIER) ? 1 : gain_vec_of(h->ctx.d.n, h->ctx.d.n);
 }
 
 int ilqr_gain_layout(const ilqr_handle *h, int32_t *vec_K, int32_t *vec_k) {

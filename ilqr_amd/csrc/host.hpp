@@ -313,12 +313,17 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
         const int mode = c.d.constraint_mode & 3;
         if constexpr (std::is_same<M, LtvModelT<T, 12, 4>>::value && DIAG) {
             // one wave per problem on the matrix unit (kernels.hpp); the lane-per-problem
-            // kernel remains for the box-QP mode and as the cross-check (ILQR_LTV_GENERIC=1)
+            // kernel remains for the barrier modes and as the cross-check (ILQR_LTV_GENERIC=1)
             static const bool generic = getenv("ILQR_LTV_GENERIC") != nullptr;
-            if (mode == 0 && !generic) {
+            if ((mode == 0 || mode == 1) && !generic) {
                 auto p = make_params<T, NX, NU>(c);
-                hipLaunchKernelGGL(ltv12x4_backward_staged_kernel<T>, dim3((c.count + 15) / 16), dim3(1024), 0, s, p);
-                hipLaunchKernelGGL(ltv12x4_backward_redo_kernel<T>, dim3(c.count), dim3(64), 0, s, p);
+                if (mode == 1) { // cilqr.py:112-134: the corner test of the box QP inside the same kernels
+                    hipLaunchKernelGGL((ltv12x4_backward_staged_kernel<T, true>), dim3((c.count + 15) / 16), dim3(1024), 0, s, p);
+                    hipLaunchKernelGGL((ltv12x4_backward_redo_kernel<T, true>), dim3(c.count), dim3(64), 0, s, p);
+                } else {
+                    hipLaunchKernelGGL((ltv12x4_backward_staged_kernel<T, false>), dim3((c.count + 15) / 16), dim3(1024), 0, s, p);
+                    hipLaunchKernelGGL((ltv12x4_backward_redo_kernel<T, false>), dim3(c.count), dim3(64), 0, s, p);
+                }
                 return hipGetLastError();
             }
         }

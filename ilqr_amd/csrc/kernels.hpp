@@ -103,6 +103,16 @@ template <class M> struct GainLayout {
     static constexpr int VK = gain_vec_of(M::NX, M::NX); // K: rows (t, i, j), j innermost
     static constexpr int Vk = gain_vec_of(M::NU, M::NX); // k: rows (t, i)
 };
+// The targets Xref interleave the same way (the n components of a time step side by side), except
+// when the constraint rows of constraints.py are bound (barrier mode, sequential QP), whose kernels
+// read the plain layout.
+template <class M, bool BARRIER> struct TargetLayout {
+    static constexpr int V = BARRIER ? 1 : gain_vec_of(M::NX, M::NX);
+};
+template <class M, bool BARRIER> __device__ __forceinline__ constexpr size_t target_x(int t, int i) {
+    constexpr int V = TargetLayout<M, BARRIER>::V;
+    return (size_t)(t * (M::NX / V) + i / V) * (size_t)(TILE * V) + (size_t)(i % V);
+}
 // offsets from a problem's pointer (tile_ptr_v): K[t][i][j] and k[t][i] with ti = t * NU + i (written so
 // that the group index needs no division of a run-time value), and the flat row r of an array with V
 // interleaved rows
@@ -443,7 +453,7 @@ __global__ __launch_bounds__(64) void cost_kernel(Params<T, M::NX, M::NU> p) {
     constexpr bool BARRIER_ = BARRIER;
     const int tile = b >> 6, ln = b & 63;
     const T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
-    const T *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
+    const T *Rt = tile_ptr_v<TargetLayout<M, BARRIER>::V>(p.Xref, tile, p.N * NX, ln);
     const T *Ut = tile_ptr(p.U, tile, (p.N - 1) * NU, ln);
     const T *Cp = BARRIER_ ? tile_ptr(p.centers, tile, p.N * 2, ln) : nullptr;
     const T *Dp = BARRIER_ ? tile_ptr(p.radius, tile, p.N, ln) : nullptr;
@@ -454,7 +464,7 @@ __global__ __launch_bounds__(64) void cost_kernel(Params<T, M::NX, M::NU> p) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             x[i] = Xt[(t * NX + i) * TILE];
-            e[i] = x[i] - Rt[(t * NX + i) * TILE];
+            e[i] = x[i] - Rt[target_x<M, BARRIER>(t, i)];
         }
 #pragma unroll
         for (int i = 0; i < NU; ++i) u[i] = Ut[(t * NU + i) * TILE];
@@ -471,7 +481,7 @@ __global__ __launch_bounds__(64) void cost_kernel(Params<T, M::NX, M::NU> p) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             x[i] = Xt[(t * NX + i) * TILE];
-            e[i] = x[i] - Rt[(t * NX + i) * TILE];
+            e[i] = x[i] - Rt[target_x<M, BARRIER>(t, i)];
         }
         T term = quad_<T, NX, DIAG>(p.Qf, e);
         if (BARRIER)
@@ -796,7 +806,7 @@ __device__ __forceinline__ int backward_sweep(const P &p, const T *Xt, const T *
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             r.x[i] = Xt[(t * NX + i) * TILE];
-            r.xr[i] = Rt[(t * NX + i) * TILE];
+            r.xr[i] = Rt[target_x<M, (CONSTR & 2) != 0>(t, i)];
         }
 #pragma unroll
         for (int i = 0; i < NU; ++i) r.u[i] = Ut[(t * NU + i) * TILE];
@@ -822,7 +832,7 @@ __device__ __forceinline__ int backward_sweep(const P &p, const T *Xt, const T *
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             x[i] = Xt[(T1 * NX + i) * TILE];
-            e[i] = x[i] - Rt[(T1 * NX + i) * TILE];
+            e[i] = x[i] - Rt[target_x<M, (CONSTR & 2) != 0>(T1, i)];
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -889,7 +899,7 @@ __device__ __forceinline__ void backward_body(const P &p, int b0) {
     constexpr bool BARRIER_ = (CONSTR & 2) != 0;
     const int tile = b0 >> 6, ln = b0 & 63; // buffers are padded to whole tiles
     const T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
-    const T *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
+    const T *Rt = tile_ptr_v<TargetLayout<M, (CONSTR & 2) != 0>::V>(p.Xref, tile, p.N * NX, ln);
     const T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
     const T *Cp = BARRIER_ ? tile_ptr(p.centers, tile, p.N * 2, ln) : nullptr;
     const T *Dp = BARRIER_ ? tile_ptr(p.radius, tile, p.N, ln) : nullptr;
@@ -944,7 +954,7 @@ __device__ __forceinline__ int backward_sweep_gen(const P &p, const T *Xt, const
 #pragma unroll
             for (int i = 0; i < NU; ++i) h.u[q][i] = Ut[(t * NU + i) * TILE];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) h.xr[q][i] = Rt[(t * NX + i) * TILE];
+            for (int i = 0; i < NX; ++i) h.xr[q][i] = Rt[target_x<M, (CONSTR & 2) != 0>(t, i)];
         }
     };
     T Vx[NX], Vxx[NX][NX];
@@ -982,7 +992,7 @@ __device__ __forceinline__ int backward_sweep_gen(const P &p, const T *Xt, const
                     for (int i = 0; i < NX; ++i) xT[i] = x[q][i];
                 }
 #pragma unroll
-            for (int i = 0; i < NX; ++i) e[i] = xT[i] - Rt[(T1 * NX + i) * TILE];
+            for (int i = 0; i < NX; ++i) e[i] = xT[i] - Rt[target_x<M, (CONSTR & 2) != 0>(T1, i)];
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 if (DIAG) {
@@ -1035,7 +1045,7 @@ __device__ __forceinline__ void backward_body_gen(const P &p, int b0) {
     const int T1 = p.N - 1;
     const int tile = b0 >> 6, ln = b0 & 63; // buffers are padded to whole tiles
     const T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
-    const T *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
+    const T *Rt = tile_ptr_v<TargetLayout<M, (CONSTR & 2) != 0>::V>(p.Xref, tile, p.N * NX, ln);
     const T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
     T *kp = tile_ptr_v<GainLayout<M>::Vk>(p.k, tile, T1 * NU, ln);
     T *Kp = tile_ptr_v<GainLayout<M>::VK>(p.K, tile, T1 * NU * NX, ln);
@@ -1204,7 +1214,43 @@ template <typename T> __device__ __forceinline__ void solve_quu4_fast(const T (&
     }
 }
 
-template <bool ASSUME_PD>
+// cilqr.py:112-134 for m = 4 with everything in one lane (the fallback sweeps): if a corner of the box
+// lo - u <= du <= hi - u satisfies the stationarity conditions of min 1/2 du'Quu du + (2 Qu)'du with
+// every multiplier beyond lambda, k = that corner and K = 0 (see riccati_step)
+template <typename T, class P>
+__device__ __forceinline__ void boxqp_corner4(const P &p, const T (&Quu)[4][4], const T (&Qu)[4], const T (&u)[4], T (&rhs)[4][2]) {
+    bool found = false;
+    T du[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+    for (int mask = 0; mask < 16; ++mask) {
+        T c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = ((mask >> j) & 1) ? (p.qhi[j] - u[j]) : (p.qlo[j] - u[j]);
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            T g = T(2) * Qu[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g = fma_(Quu[i][j], c[j], g);
+            const T y = -g;
+            ok = ok && (((mask >> i) & 1) ? (y > p.lambda) : (y < -p.lambda));
+        }
+        if (ok && !found) {
+            found = true;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) du[j] = c[j];
+        }
+    }
+    if (found) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rhs[i][0] = du[i];
+            rhs[i][1] = T(0);
+        }
+    }
+}
+
+template <bool ASSUME_PD, bool BOXQP = false>
 __device__ __forceinline__ int ltv12x4_backward_sweep(const Params<double, 12, 4> &p, double *sh, int slot, int lane, bool &bad) {
     constexpr int NX = 12, NU = 4;
     const int c = lane & 15, g = lane >> 4;
@@ -1302,6 +1348,12 @@ __device__ __forceinline__ int ltv12x4_backward_sweep(const Params<double, 12, 4
             solve_quu4_fast<double>(Quu, rhs, bad);
         else
             status |= solve_quu<double, NU, 2, false>(Quu, rhs, bad);
+        if (BOXQP) {
+            double uj[NU];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) uj[j] = __shfl(xu_c, NX + j);
+            boxqp_corner4<double>(p, Quu, Qu, uj, rhs);
+        }
         const double kg = g == 0 ? rhs[0][1] : g == 1 ? rhs[1][1] : g == 2 ? rhs[2][1] : rhs[3][1]; // K[g][c]
         const double kc = cu == 0 ? rhs[0][0] : cu == 1 ? rhs[1][0] : cu == 2 ? rhs[2][0] : rhs[3][0]; // k[cu]
         if (outOn) outP[(size_t)t * outS] = isx ? kg : kc;
@@ -1327,7 +1379,7 @@ __device__ __forceinline__ int ltv12x4_backward_sweep(const Params<double, 12, 4
 // own.  The rank-4 update K'Qux contracts over lane group 0 and takes four calls.
 typedef float v4f32_ __attribute__((ext_vector_type(4)));
 
-template <bool ASSUME_PD>
+template <bool ASSUME_PD, bool BOXQP = false>
 __device__ __forceinline__ int ltv12x4_backward_sweep(const Params<float, 12, 4> &p, float *sh, int slot, int lane, bool &bad) {
     constexpr int NX = 12, NU = 4;
     const int c = lane & 15, g = lane >> 4;
@@ -1416,6 +1468,12 @@ __device__ __forceinline__ int ltv12x4_backward_sweep(const Params<float, 12, 4>
             rhs[i][1] = -DG[i]; // lane (c, 3), c < 12: -Qux[i][c]
         }
         status |= solve_quu<float, NU, 2, ASSUME_PD>(Quu, rhs, bad);
+        if (BOXQP) {
+            float uj[NU];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) uj[j] = __shfl(xu_c, NX + j);
+            boxqp_corner4<float>(p, Quu, Qu, uj, rhs);
+        }
         if (g3 && isx) {
 #pragma unroll
             for (int q = 0; q < NU; ++q) Kp[(size_t)((t * NU + q) * NX + c) * TILE] = rhs[q][1];
@@ -1494,7 +1552,9 @@ template <> struct Mfma4<float> {
 // to HBM, as partial lines, and was held to a third of the speed.)  Problems of the 16 that are not
 // selected keep their stored gains: the writing lanes skip their parts of the granules.  A problem
 // whose Quu was not positive definite somewhere is flagged in p.redo for the fallback launch.
-template <typename T> __global__ __launch_bounds__(1024) void ltv12x4_backward_staged_kernel(Params<T, 12, 4> p) {
+// BOXQP (cilqr.py:112-134): lane (ci, g) tests row g of the stationarity conditions of corner ci of the
+// box, one ballot tells which corners pass, and the first one replaces the gains by k = corner, K = 0.
+template <typename T, bool BOXQP = false> __global__ __launch_bounds__(1024) void ltv12x4_backward_staged_kernel(Params<T, 12, 4> p) {
     using St = LtvStage<T>;
     using MF = Mfma4<T>;
     using acc = typename MF::acc;
@@ -1502,7 +1562,8 @@ template <typename T> __global__ __launch_bounds__(1024) void ltv12x4_backward_s
     constexpr int IN_ROWS = 28, OUT_ROWS = 52, AGR = NX * NX * ES / 16, TBL = NX * (NX + NU) * ES / 16;
     constexpr int NLOAD = (IN_ROWS * GPR + TBL + 63) / 64, NSTORE = (OUT_ROWS * GPR + 63) / 64; // waves that load / that store
     constexpr int IN_BYTES = NLOAD * 1024, OUT_BYTES = NSTORE * 1024;
-    constexpr int OFF_OUT = D * S * IN_BYTES, OFF_SH = OFF_OUT + 2 * S * OUT_BYTES, OFF_FLAG = OFF_SH + 16 * 16 * ES;
+    constexpr int SHW = 24; // words of a wave's own LDS: Quu (16), the step's inputs (4, BOXQP)
+    constexpr int OFF_OUT = D * S * IN_BYTES, OFF_SH = OFF_OUT + 2 * S * OUT_BYTES, OFF_FLAG = OFF_SH + 16 * SHW * ES;
     static_assert(NLOAD + NSTORE <= 16 && D % 2 == 0, "wave roles, image parity");
     __shared__ __attribute__((aligned(16))) unsigned char lds[OFF_FLAG + 64];
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
@@ -1590,7 +1651,8 @@ template <typename T> __global__ __launch_bounds__(1024) void ltv12x4_backward_s
     const unsigned oF = IN_ROWS * GPR * 16 + (isx ? (g * NX + ci) * ES : NX * NX * ES + (g * NU + cu) * ES), oFk = isx ? 4 * NX * ES : 4 * NU * ES;
     const unsigned ogain = St::off(isx ? g * NX + ci : 48 + g, w);
     const bool gain_on = isx || ci == NX;
-    T *sh = (T *)(lds + OFF_SH) + w * 16; // Quu of this wave's problem, row-major
+    T *sh = (T *)(lds + OFF_SH) + w * SHW; // Quu of this wave's problem, row-major; then the inputs of the step
+    const T qlo_g = p.qlo[g], qhi_g = p.qhi[g];
     // lane (i, j) = (ci, g), i < 4, computes entry (i, j) of the inverse = cofactor (j, i) / det: the
     // entry (j, i) of Quu and the nine entries of the rows j+1.. and the columns i+1.. (cyclically)
     int oq[10];
@@ -1630,6 +1692,7 @@ template <typename T> __global__ __launch_bounds__(1024) void ltv12x4_backward_s
         // first, takes the 3 x 3 determinant of the rest (the minor: a rotation of three rows is even)
         // and the four lanes j of an i add up a_ji C_ji to the determinant (expansion along column i).
         if (!isx) sh[cu * 4 + g] = TG[3];
+        if (BOXQP && !isx && g == 0) sh[16 + cu] = xu_c;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1661,7 +1724,29 @@ template <typename T> __global__ __launch_bounds__(1024) void ltv12x4_backward_s
         const T qg = TG[3];
         acc R = {T(0), T(0), T(0), T(0)};
         R = MF::run(inv_e, ci == NX ? qug : qg, R);
-        const T kg = -R[0]; // K[g][ci] (ci < 12), k[g] (ci == 12)
+        T kg = -R[0]; // K[g][ci] (ci < 12), k[g] (ci == 12)
+        if (BOXQP) {
+            T uj[NU], gg = T(2) * qug;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                uj[j] = sh[16 + j];
+                const T cj = ((ci >> j) & 1) ? p.qhi[j] - uj[j] : p.qlo[j] - uj[j];
+                gg = fma_(sh[g * 4 + j], cj, gg);
+            }
+            const T y = -gg;
+            const bool okr = ((ci >> g) & 1) ? (y > p.lambda) : (y < -p.lambda);
+            const unsigned long long bm = __ballot(okr);
+            const unsigned okc = (unsigned)(bm & (bm >> 16) & (bm >> 32) & (bm >> 48)) & 0xffffu; // bit c: corner tau(c) passes
+            int corner = -1;
+#pragma unroll
+            for (int cm = 15; cm >= 0; --cm)
+                if ((okc >> MF::tau(cm)) & 1u) corner = cm; // the lowest passing corner, as the serial test finds it
+            if (corner >= 0) { // (uniform over the wave)
+                const T ug = g == 0 ? uj[0] : g == 1 ? uj[1] : g == 2 ? uj[2] : uj[3];
+                const T dug = ((corner >> g) & 1) ? qhi_g - ug : qlo_g - ug;
+                kg = ci == NX ? dug : T(0);
+            }
+        }
         if (gain_on) *(T *)(out + ogain) = kg;
         // Vx = Qx + K' Qu ; Vxx = Qxx + K' Qux (ilqr.py:104-105)
         T kq = kg * qug;
@@ -1724,7 +1809,7 @@ template <typename T> __global__ __launch_bounds__(1024) void ltv12x4_backward_s
 // in p.redo, one wave per workgroup each, with the pivoted-LU solve of the lane-per-problem kernel
 // (ilqr.py:99 inverts Quu whatever its signs).  A kernel of its own, so that the fallback's
 // registers do not cost the main kernel its occupancy.
-template <typename T> __global__ __launch_bounds__(64) void ltv12x4_backward_redo_kernel(Params<T, 12, 4> p) {
+template <typename T, bool BOXQP = false> __global__ __launch_bounds__(64) void ltv12x4_backward_redo_kernel(Params<T, 12, 4> p) {
     __shared__ T sh[80];
     const int lane = threadIdx.x;
     const int slot = blockIdx.x;
@@ -1733,7 +1818,7 @@ template <typename T> __global__ __launch_bounds__(64) void ltv12x4_backward_red
     if (p.select_converged ? (p.converged[o] == 0 || p.carried[o] == 0) : p.converged[o] != 0) return;
     if (p.redo[o] == 0) return;
     bool bad = false;
-    const int status = ltv12x4_backward_sweep<false>(p, sh, slot, lane, bad);
+    const int status = ltv12x4_backward_sweep<false, BOXQP>(p, sh, slot, lane, bad);
     if (lane == 0 && status != 0 && p.status) p.status[o] |= status;
 }
 
@@ -1853,7 +1938,7 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             if (!REROLL) r.xp[i] = Xt[(t * NX + i) * TILE];
-            r.xr[i] = Rt[(t * NX + i) * TILE];
+            r.xr[i] = Rt[target_x<M, BARRIER>(t, i)];
         }
         if (BARRIER) {
             r.cx = Cp[(t * 2 + 0) * TILE];
@@ -1951,7 +2036,7 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
         // terminal term (ilqr.py:44-45)
         T xr[NX], cx = T(0), cy = T(0), rad = T(0);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xr[i] = Rt[(T1 * NX + i) * TILE];
+        for (int i = 0; i < NX; ++i) xr[i] = Rt[target_x<M, BARRIER>(T1, i)];
         if (BARRIER) {
             cx = Cp[(T1 * 2 + 0) * TILE];
             cy = Cp[(T1 * 2 + 1) * TILE];
@@ -2013,7 +2098,7 @@ __device__ __forceinline__ void evaluate_body(const P &p, int end, int wave, int
     const T Jcur = p.J[o];
     const int tile = b >> 6, ln = b & 63;
     const T *Xt = tile_ptr(p.X, tile, p.N * NX, ln);
-    const T *Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
+    const T *Rt = tile_ptr_v<TargetLayout<M, BARRIER>::V>(p.Xref, tile, p.N * NX, ln);
     const T *Ut = tile_ptr(p.U, tile, T1 * NU, ln);
     const T *Cp = BARRIER ? tile_ptr(p.centers, tile, p.N * 2, ln) : nullptr;
     const T *Dp = BARRIER ? tile_ptr(p.radius, tile, p.N, ln) : nullptr;
@@ -2130,7 +2215,7 @@ template <typename T, class M, bool BARRIER, int L, bool REROLL> struct ListedPi
         fetch<GainLayout<M>::Vk>(kp, t0 * NU, C::nk, T1 * NU, st.k);
         fetch(Ut, t0 * NU, C::nk, T1 * NU, st.U);
         if (!REROLL) fetch(Xt, t0 * NX, C::nX, N * NX, st.X);
-        fetch(Rt, t0 * NX, C::nX, N * NX, st.R);
+        fetch<TargetLayout<M, BARRIER>::V>(Rt, t0 * NX, C::nX, N * NX, st.R);
         if (BARRIER) {
             fetch(Cp, t0 * 2, C::nC, N * 2, st.Cc);
             fetch(Dp, t0, C::nD, N, st.D);
@@ -2215,7 +2300,7 @@ __device__ __forceinline__ void listed_rounds(const P &p, const ListedPipe<T, M,
         }
         T xr[NX], cx = T(0), cy = T(0), rad = T(0);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xr[i] = pipe.Rt[(T1 * NX + i) * TILE];
+        for (int i = 0; i < NX; ++i) xr[i] = pipe.Rt[target_x<M, BARRIER>(T1, i)];
         if (BARRIER) {
             cx = pipe.Cp[(T1 * 2 + 0) * TILE];
             cy = pipe.Cp[(T1 * 2 + 1) * TILE];
@@ -2319,7 +2404,7 @@ __global__ __launch_bounds__(64) void evaluate_listed_kernel(Params<T, M::NX, M:
     const int tile = b >> 6, ln = b & 63;
     ListedPipe<T, M, BARRIER, L, REROLL> pipe;
     pipe.Xt = tile_ptr(p.X, tile, p.N * NX, ln);
-    pipe.Rt = tile_ptr(p.Xref, tile, p.N * NX, ln);
+    pipe.Rt = tile_ptr_v<TargetLayout<M, BARRIER>::V>(p.Xref, tile, p.N * NX, ln);
     pipe.Ut = tile_ptr(p.U, tile, T1 * NU, ln);
     pipe.Cp = BARRIER ? tile_ptr(p.centers, tile, p.N * 2, ln) : nullptr;
     pipe.Dp = BARRIER ? tile_ptr(p.radius, tile, p.N, ln) : nullptr;
@@ -3203,18 +3288,18 @@ template <typename T> __global__ __launch_bounds__(64) void repack_move_kernel(R
     while (q + 1 < a.narr && (int)blockIdx.y >= a.arr[q + 1].chunk0) ++q;
     const RepackArray<T> r = a.arr[q];
     const int i0 = ((int)blockIdx.y - r.chunk0) * REPACK_CHUNK;
-    T *dst = act ? r.dst_active + (size_t)(ns >> 6) * r.rows * TILE + (ns & 63) : nullptr;
-    const T *src = r.src + (size_t)tile * r.rows * TILE + lane;
+    T *dst = act ? r.dst_active + (size_t)(ns >> 6) * r.rows * TILE : nullptr;
+    const T *src = r.src + (size_t)tile * r.rows * TILE;
     T v[REPACK_CHUNK];
 #pragma unroll
     for (int j = 0; j < REPACK_CHUNK; ++j) {
         const int i = i0 + j < r.rows ? i0 + j : r.rows - 1; // no branch around the loads
-        v[j] = src[(size_t)i * TILE];
+        v[j] = src[tile_elem(i, lane, r.vshift)];
     }
     if (dst) {
 #pragma unroll
         for (int j = 0; j < REPACK_CHUNK; ++j)
-            if (i0 + j < r.rows) dst[(size_t)(i0 + j) * TILE] = v[j];
+            if (i0 + j < r.rows) dst[tile_elem(i0 + j, ns & 63, r.vshift)] = v[j];
     }
 }
 

@@ -62,8 +62,8 @@ class RecedingHorizon:
         main = torch.cuda.current_stream(d.device)
         if self._ready is not None:
             main.wait_event(self._ready)
-            _lib.check(d.lib.ilqr_to_tiled(self._staged.data_ptr(), d.Xref.data_ptr(), self.B, self.N * self.n,
-                                           d.np_dtype.itemsize, d.stream()), "ilqr_to_tiled")
+            _lib.check(d.lib.ilqr_to_tiled_v(self._staged.data_ptr(), d.Xref.data_ptr(), self.B, self.N * self.n,
+                                             d.np_dtype.itemsize, d.target_layout(), d.stream()), "ilqr_to_tiled_v")
             self._consumed = torch.cuda.Event()
             self._consumed.record(main)
             self._ready = None

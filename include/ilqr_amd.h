@@ -18,8 +18,8 @@
  *   Xref   rows = N*n        target_states     (ilqr.py:18)
  *   K      rows = (N-1)*m*n  feedback gains    (ilqr.py:78  self.K)
  *   k      rows = (N-1)*m    feed-forward      (ilqr.py:77  self.k)
- *          The two gain arrays interleave V consecutive rows of a problem (ilqr_gain_layout; V = 1,
- *          2 or 4): [ceil(B/64)][rows/V][64][V], element (b, r) at
+ *          The two gain arrays and Xref interleave V consecutive rows of a problem (ilqr_gain_layout,
+ *          ilqr_target_layout; V = 1, 2 or 4): [ceil(B/64)][rows/V][64][V], element (b, r) at
  *          ((b/64)*(rows/V) + r/V)*64*V + (b%64)*V + r%V.  Convert with ilqr_to_tiled_v /
  *          ilqr_from_tiled_v.  V = 1 is the plain layout above.
  *   centers rows = N*2, radius rows = N        (constraints.py:15-18, per problem)
@@ -326,6 +326,9 @@ int ilqr_to_tiled_v(const void *aos, void *tiled, int32_t B, int32_t rows, int32
 int ilqr_from_tiled_v(const void *tiled, void *aos, int32_t B, int32_t rows, int32_t elem_bytes, int32_t vec, void *stream);
 /* rows interleaved per problem in this handle's K and k buffers (a function of n and m only) */
 int ilqr_gain_layout(const ilqr_handle *h, int32_t *vec_K, int32_t *vec_k);
+/* ... and in its Xref buffer (target_states, ilqr.py:18): a function of n, and 1 whenever the handle
+ * has the constraint rows bound (ILQR_CONSTR_BARRIER: barrier mode and the sequential-QP solver) */
+int32_t ilqr_target_layout(const ilqr_handle *h);
 
 const char *ilqr_strerror(int code);
 /* hipError_t of the last failing HIP call on this thread (0 if none) */

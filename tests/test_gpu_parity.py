@@ -587,6 +587,53 @@ def test_ltv12x4_matches_oracle(ilqr_cls, oracle, limits):
         assert np.array_equal(opt.alpha_history[b, :n][solid_o[:n]], r["hist_alpha"][b, :n][solid_o[:n]])
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_cilqr_on_ltv12x4_matches_oracle(oracle, dtype):
+    """cilqr.py:87-139 on the n = 12, m = 4 table model: the box-QP corner test runs inside the
+    matrix-unit backward kernels.  Parity UNPINNED towards the reference (OSQP is absent; the reference
+    has no model of this size either): the checker is the oracle's statement of cilqr.py with an exact QP."""
+    from ilqr_amd import problems, systems
+    from ilqr_amd.cilqr import iterative_LQR as CILQR
+    N, B = 120, 70
+    A, Bm, Q, R = problems.ltv_system(N=N)
+    s = systems.LTVSystem(A, Bm, dt=0.05)
+    s.set_cost(Q, R)
+    s.set_control_limit([-1.0] * 4, [1.0] * 4)        # tight enough that all four bounds are active at most steps of the first pass
+    p = problems.ltv_batch(B, N)
+    opt = CILQR(s, p["target_states"], s.dt, history=True, dtype=dtype)
+    opt.inputs, opt.states = p["init_inputs"].copy(), p["init_states"].copy()
+    dev = opt.upload()
+    dev.initial_cost()
+    dev.backward()
+    d = oracle.make_desc(s, N, max_iter=100, alpha_floor=1e-2, solver_control_limited=True)
+    tol = 1e-11 if dtype == np.float64 else 2e-3
+    fired = 0
+    for b in (0, 33, 69):
+        Ko, ko, rc = oracle.backward(d, np.ascontiguousarray(p["target_states"][b]), p["init_states"][b].copy(),
+                                     p["init_inputs"][b].copy())
+        assert rc == 0
+        zero = np.abs(Ko).sum(axis=(1, 2)) == 0
+        fired += int(zero.sum())
+        Kg, kg = dev.download_K()[b], dev.download_k()[b][:, :, 0]
+        if dtype == np.float64:
+            assert np.array_equal(np.abs(Kg).sum(axis=(1, 2)) == 0, zero)   # the same steps take the corner
+        assert nrm(Kg, Ko) <= tol and nrm(kg, ko) <= tol
+    assert fired > 0      # the branch must fire in this fixture, or the test proves nothing
+    opt()
+    r = oracle.solve_batch(d, p["target_states"], p["init_states"].copy(), p["init_inputs"].copy())
+    assert np.all(opt.status == 0)
+    ctol = 1e-9 if dtype == np.float64 else 2e-4
+    for b in range(B):
+        ro = int(r["iters"][b])
+        solid_o = noise_floor_mask(r["hist_cost"][b, :ro], r["cost0"][b], rel=1e-12 if dtype == np.float64 else 1e-4)
+        last_solid = int(np.nonzero(solid_o)[0].max()) + 1 if solid_o.any() else 0
+        n = min(int(opt.iterations[b]), ro, last_solid)
+        assert int(opt.iterations[b]) >= min(ro, last_solid)
+        if n:
+            rel = np.abs(opt.cost_history[b, :n] - r["hist_cost"][b, :n]) / np.abs(r["hist_cost"][b, :n])
+            assert rel.max() <= ctol, (b, rel.max())
+
+
 def test_ltv12x4_indefinite_quu_uses_the_fallback_launch(ilqr_cls, oracle):
     """The matrix-unit backward kernel of the n = 12 model solves Quu branch-free and flags the
     problems in which a pivot was not positive; a second launch repeats those with the pivoted-LU

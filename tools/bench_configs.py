@@ -2,7 +2,7 @@
 """Whole-solve timings of the secondary workloads (the ones bench.py does not quote): one JSON
 line per configuration, inputs resident in HBM, time = ilqr_solve on the device, median of reps.
 
-    python tools/bench_configs.py [--reps 3] [--only car4096,car8192,car16384,car32768,cilqr16384,car65536_f32,ltv_f64,ltv_f32,sqp16384,sqp65536]
+    python tools/bench_configs.py [--reps 3] [--only car4096,car8192,car16384,car32768,cilqr16384,car65536_f32,ltv_f64,ltv_f32,cilqr_ltv_f64,cilqr_ltv_f32,sqp16384,sqp65536]
 
 car8192 / car16384 / car32768 are the per-GPU shards of the 65536-problem headline batch on 8 / 4 / 2 GPUs.
 """
@@ -59,6 +59,17 @@ def build(name):
         opt = iterative_LQR(s, p["target_states"], 0.05, dtype=np.float32 if name.endswith("f32") else np.float64)
         opt.inputs, opt.states = p["init_inputs"], p["init_states"]
         return opt, f"LTV n=12 m=4, B={B}, N={N}, maxIter=30, {'fp32' if name.endswith('f32') else 'fp64'}"
+    if name in ("cilqr_ltv_f64", "cilqr_ltv_f32"):
+        # cilqr.py:87-139 (box QP in the backward pass, 8 step sizes, maxIter 100) on the table model
+        B, N = 32768, 500
+        A, Bm, Q, R = problems.ltv_system(N=N)
+        s = systems.LTVSystem(A, Bm, dt=0.05)
+        s.set_cost(Q, R)
+        s.set_control_limit([-2.0] * 4, [2.0] * 4)
+        p = problems.ltv_batch(B, N)
+        opt = CILQR(s, p["target_states"], 0.05, dtype=np.float32 if name.endswith("f32") else np.float64)
+        opt.inputs, opt.states = p["init_inputs"], p["init_states"]
+        return opt, f"cilqr: LTV n=12 m=4, box QP, B={B}, N={N}, maxIter=100, 8 step sizes, {'fp32' if name.endswith('f32') else 'fp64'}"
     if name in ("sqp16384", "sqp65536"):
         from ilqr_amd.sqp import sequential_QP_optimizer
         B, N = int(name[3:]), 80
