@@ -374,6 +374,14 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
                 return hipGetLastError();
             }
         }
+        // one lane per problem: the rows travel through a ring in LDS (EvalRing), several steps ahead
+        if constexpr (L == 1 && REROLL && !BARRIER && EvalRing<T, M>::OK) {
+            static const bool no_ring = getenv("ILQR_NO_LDS_RING") != nullptr;
+            if (!no_ring) {
+                hipLaunchKernelGGL((evaluate_kernel<T, M, DIAG, BARRIER, L, A, REROLL, false, false, true>), dim3(blocks), dim3(256), 0, s, p, first_end);
+                return hipGetLastError();
+            }
+        }
         hipLaunchKernelGGL((evaluate_kernel<T, M, DIAG, BARRIER, L, A, REROLL>), dim3(blocks), dim3(256), 0, s, p, first_end);
         return hipGetLastError();
     }

@@ -1867,6 +1867,30 @@ __device__ __forceinline__ void control_update(const P &p, T alpha, const T (&x)
     }
 }
 
+// Row prefetch of the first line-search stage through LDS (one lane per problem): the rows of a time
+// step (K, k, U, Xref: 8 KiB per wave for the Car in fp64) are contiguous per array, so the wave
+// fetches them with direct-to-LDS loads of 1 KiB each, EVAL_RING - 1 steps ahead of their use,
+// into a ring of its own, and every lane then reads its values of the step from there.  In registers
+// the same rows cost 32 VGPRs per step in flight, and with the six candidates' states a second step
+// in flight no longer fits: the compiler then issues the loads late in the step before, and the wave
+// waits for memory in a sixth of its cycles.
+constexpr int EVAL_RING = 4;
+template <typename T, class M> struct EvalRing {
+    static constexpr int G = 16 / (int)sizeof(T);                  // elements per 16-byte granule
+    static constexpr int WE = TILE * G;                            // elements a wave instruction moves
+    static constexpr int KE = M::NU * M::NX * TILE, kE = M::NU * TILE, UE = M::NU * TILE, RE = M::NX * TILE; // per step
+    static constexpr int oK = 0, ok = KE, oU = KE + kE, oR = KE + kE + UE, STEP = KE + kE + UE + RE;
+    static constexpr int NLD = STEP / WE;                          // loads per step
+    static constexpr int BYTES = EVAL_RING * STEP * (int)sizeof(T); // per wave
+    // whole wave instructions per array, and the rings of a workgroup's four waves within 128 KiB of LDS
+    static constexpr bool OK = M::NX <= 8 && KE % WE == 0 && kE % WE == 0 && UE % WE == 0 && RE % WE == 0 && 4 * BYTES <= 131072;
+};
+template <typename T> struct EvalTile { // what the LDS path needs beside the per-lane pointers
+    const T *K = nullptr, *k = nullptr, *U = nullptr, *R = nullptr; // the wave's tile of each array
+    unsigned char *ring = nullptr;                                   // the wave's own ring
+    int lane = 0;
+};
+
 template <typename T, int NX, int NU> struct FwdRow { // rows of one step shared by all step sizes of a problem
     T K[NU][NX], k[NU], xp[NX], up[NU], xr[NX], cx, cy, rad, s, c;
 };
@@ -1920,12 +1944,15 @@ __device__ __forceinline__ T candidate_total(const P &p, const T (&x)[M::NX], co
 // turns its re-rollout into a few multiply-adds.
 // CKPT: the state of every candidate at the start of every segment of COMMIT_SEG time steps is
 // stored to CKp (this problem's first checkpoint slot, see Params::CK) by the lanes with `ck_store`.
-template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool REROLL, bool FAST, bool TC = false, bool CKPT = false, class P>
+// LDSR: the rows come through the wave's LDS ring (EvalRing; L = 1, REROLL, no constraint rows, no cache).
+template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool REROLL, bool FAST, bool TC = false, bool CKPT = false,
+          bool LDSR = false, class P>
 __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T *Rt, const T *Ut, const T *Kp, const T *kp,
                                                 const T *Cp, const T *Dp, int al, bool active, T Jcur, int base0, int end,
                                                 int &best, T &best_cost, bool &bad, const T *SCp = nullptr, T *CKp = nullptr,
-                                                bool ck_store = false) {
+                                                bool ck_store = false, EvalTile<T> et = EvalTile<T>()) {
     constexpr int NX = M::NX, NU = M::NU;
+    static_assert(!LDSR || (L == 1 && REROLL && !BARRIER && !TC && !CKPT && EvalRing<T, M>::OK), "LDS row ring: see EvalRing");
     const int T1 = p.N - 1;
     auto load_row = [&](int t, FwdRow<T, NX, NU> &r) {
 #pragma unroll
@@ -1969,7 +1996,7 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
 #pragma unroll
         for (int i = 0; i < NX; ++i) xq[i] = Xt[i * TILE];
         FwdRow<T, NX, NU> nxt;
-        load_row(0, nxt);
+        if (!LDSR) load_row(0, nxt);
         auto one_step = [&](int t, FwdRow<T, NX, NU> &r) {
             if (REROLL) {
 #pragma unroll
@@ -1984,7 +2011,53 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
                 for (int i = 0; i < NX; ++i) xq[i] = xqn[i];
             }
         };
-        if (CKPT) {
+        if constexpr (LDSR) {
+            using ER = EvalRing<T, M>;
+            T *const img0 = (T *)et.ring;
+            const int lane = et.lane;
+            // the rows of step t (past the end: of the last step again, so that the count of loads in
+            // flight stays what the waits below assume) into ring slot `slot`
+            auto issue = [&](int t, int slot) {
+                const size_t tt = (size_t)(t < T1 ? t : T1 - 1);
+                T *dst = img0 + slot * ER::STEP;
+#pragma unroll
+                for (int q = 0; q < ER::KE / ER::WE; ++q) glds16(et.K + tt * ER::KE + q * ER::WE + lane * ER::G, dst + ER::oK + q * ER::WE);
+#pragma unroll
+                for (int q = 0; q < ER::kE / ER::WE; ++q) glds16(et.k + tt * ER::kE + q * ER::WE + lane * ER::G, dst + ER::ok + q * ER::WE);
+#pragma unroll
+                for (int q = 0; q < ER::UE / ER::WE; ++q) glds16(et.U + tt * ER::UE + q * ER::WE + lane * ER::G, dst + ER::oU + q * ER::WE);
+#pragma unroll
+                for (int q = 0; q < ER::RE / ER::WE; ++q) glds16(et.R + tt * ER::RE + q * ER::WE + lane * ER::G, dst + ER::oR + q * ER::WE);
+            };
+            auto read_row = [&](int slot, FwdRow<T, NX, NU> &r) {
+                const T *img = img0 + slot * ER::STEP;
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    r.k[i] = img[ER::ok + gain_k<M>(0, i) + lane * GainLayout<M>::Vk];
+                    r.up[i] = img[ER::oU + i * TILE + lane];
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) r.K[i][j] = img[ER::oK + gain_K<M>(i, j) + lane * GainLayout<M>::VK];
+                }
+#pragma unroll
+                for (int i = 0; i < NX; ++i) r.xr[i] = img[ER::oR + target_x<M, false>(0, i) + lane * TargetLayout<M, false>::V];
+                r.cx = r.cy = r.rad = r.s = r.c = T(0);
+            };
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // (nothing of an earlier sweep still touches the ring)
+#pragma unroll
+            for (int q = 0; q < EVAL_RING - 1; ++q) issue(q, q);
+            int slot = 0;
+            for (int t = 0; t < T1; ++t) {
+                // in flight: the steps t .. t + EVAL_RING - 2; loads complete in order
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((EVAL_RING - 2) * ER::NLD) : "memory");
+                const int refill = slot == 0 ? EVAL_RING - 1 : slot - 1; // the slot step t - 1 was read from
+                issue(t + EVAL_RING - 1, refill);
+                FwdRow<T, NX, NU> r;
+                read_row(slot, r);
+                one_step(t, r);
+                slot = slot + 1 == EVAL_RING ? 0 : slot + 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (CKPT) {
             // The horizon in segments.  The first step of a segment also stores the candidates'
             // states (the segment's checkpoint), AFTER it has issued the loads of the next row: loads
             // and stores retire in order, so stores issued before them would make the next step wait
@@ -2078,8 +2151,8 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
 // (evaluate_listed_kernel) walks that list with the remaining candidates.  Candidates are still
 // examined in increasing index order, so the result is that of the serial search.
 // (body of evaluate_kernel: the work of wave number `wave` of the launch)
-template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool REROLL, bool TC = false, bool CKPT = false, class P>
-__device__ __forceinline__ void evaluate_body(const P &p, int end, int wave, int lane) {
+template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool REROLL, bool TC = false, bool CKPT = false, bool LDSR = false, class P>
+__device__ __forceinline__ void evaluate_body(const P &p, int end, int wave, int lane, unsigned char *ring = nullptr) {
     constexpr int NX = M::NX, NU = M::NU;
     constexpr int PPW = 64 / L; // problems per wave
     const int pl = lane / L, al = lane % L;
@@ -2110,8 +2183,17 @@ __device__ __forceinline__ void evaluate_body(const P &p, int end, int wave, int
     const T *SCp = (REROLL && TC) ? tile_ptr(p.SC, tile, T1 * 2, ln) : nullptr;
     const int nseg = (T1 + COMMIT_SEG - 1) / COMMIT_SEG;
     T *CKp = CKPT ? tile_ptr(p.CK, tile, nseg * CK_CANDIDATES * NX, ln) : nullptr;
-    evaluate_rounds<T, M, DIAG, BARRIER, L, A, REROLL, true, TC, CKPT>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, 0, end, best, best_cost,
-                                                                        bad, SCp, CKp, true);
+    EvalTile<T> et;
+    if constexpr (LDSR) { // (L = 1: the wave's problems are the tile `wave`)
+        et.K = p.K + (size_t)wave * (T1 * NU * NX) * TILE;
+        et.k = p.k + (size_t)wave * (T1 * NU) * TILE;
+        et.U = p.U + (size_t)wave * (T1 * NU) * TILE;
+        et.R = p.Xref + (size_t)wave * (p.N * NX) * TILE;
+        et.ring = ring;
+        et.lane = lane;
+    }
+    evaluate_rounds<T, M, DIAG, BARRIER, L, A, REROLL, true, TC, CKPT, LDSR>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, 0, end, best,
+                                                                              best_cost, bad, SCp, CKp, true, et);
     // an angle outside the fast trigonometric range anywhere in the wave: redo with the library
     // routine; a problem one of whose lanes saw such an angle takes the redone result (and tells
     // the commit kernel to use the library routine too), the others keep theirs, so a problem's
@@ -2124,8 +2206,8 @@ __device__ __forceinline__ void evaluate_body(const P &p, int end, int wave, int
         T best_cost2;
         bool bad2 = false;
         // (the checkpoints of the problems that take the redone result are replaced, the others' stay)
-        evaluate_rounds<T, M, DIAG, BARRIER, L, A, REROLL, false, TC, CKPT>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, 0, end, best2,
-                                                                             best_cost2, bad2, SCp, CKp, pbad);
+        evaluate_rounds<T, M, DIAG, BARRIER, L, A, REROLL, false, TC, CKPT, LDSR>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, 0, end, best2,
+                                                                                   best_cost2, bad2, SCp, CKp, pbad, et);
         best = pbad ? best2 : best;
         best_cost = pbad ? best_cost2 : best_cost;
     }
@@ -2149,9 +2231,15 @@ __device__ __forceinline__ void evaluate_body(const P &p, int end, int wave, int
     }
 }
 
-template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool REROLL, bool TC = false, bool CKPT = false>
+template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool REROLL, bool TC = false, bool CKPT = false, bool LDSR = false>
 __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T, M::NX, M::NU> p, int end) {
-    evaluate_body<T, M, DIAG, BARRIER, L, A, REROLL, TC, CKPT>(p, end, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), threadIdx.x & 63);
+    if constexpr (LDSR) {
+        __shared__ __attribute__((aligned(16))) unsigned char ring[4 * EvalRing<T, M>::BYTES];
+        const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        evaluate_body<T, M, DIAG, BARRIER, L, A, REROLL, TC, CKPT, true>(p, end, blockIdx.x * 4 + w, threadIdx.x & 63, ring + w * EvalRing<T, M>::BYTES);
+    } else {
+        evaluate_body<T, M, DIAG, BARRIER, L, A, REROLL, TC, CKPT>(p, end, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), threadIdx.x & 63);
+    }
 }
 
 // ---------------------------------------------------------------- evaluate, stage two
