@@ -375,10 +375,10 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
             }
         }
         // one lane per problem: the rows travel through a ring in LDS (EvalRing), several steps ahead
-        if constexpr (L == 1 && REROLL && !BARRIER && EvalRing<T, M>::OK) {
+        if constexpr ((L == 1 || L == 2) && REROLL && !BARRIER && EvalRing<T, M, L>::OK) {
             static const bool no_ring = getenv("ILQR_NO_LDS_RING") != nullptr;
             if (!no_ring) {
-                hipLaunchKernelGGL((evaluate_kernel<T, M, DIAG, BARRIER, L, A, REROLL, false, false, true>), dim3(blocks), dim3(256), 0, s, p, first_end);
+                hipLaunchKernelGGL((evaluate_ring_kernel<T, M, DIAG, L, A>), dim3(blocks), dim3(256), 0, s, p, first_end);
                 return hipGetLastError();
             }
         }

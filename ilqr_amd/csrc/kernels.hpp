@@ -1875,20 +1875,45 @@ __device__ __forceinline__ void control_update(const P &p, T alpha, const T (&x)
 // in flight no longer fits: the compiler then issues the loads late in the step before, and the wave
 // waits for memory in a sixth of its cycles.
 constexpr int EVAL_RING = 4;
-template <typename T, class M> struct EvalRing {
-    static constexpr int G = 16 / (int)sizeof(T);                  // elements per 16-byte granule
-    static constexpr int WE = TILE * G;                            // elements a wave instruction moves
-    static constexpr int KE = M::NU * M::NX * TILE, kE = M::NU * TILE, UE = M::NU * TILE, RE = M::NX * TILE; // per step
+// (L lanes per problem: a wave works on the 64 / L problems of a part of a tile, whose values of a row
+// group are PPW * V contiguous elements; a load instruction gathers 64 granules of 16 bytes, one per
+// lane, from wherever they are, and LDS receives them in lane order: the step's image in LDS is the
+// wave's granules of K, k, U and Xref in that order, row group by row group.)
+template <typename T, class M, int L> struct EvalRing {
+    static constexpr int G = 16 / (int)sizeof(T);                   // elements per 16-byte granule
+    static constexpr int PPW = TILE / L;                            // problems per wave
+    static constexpr int VK = GainLayout<M>::VK, Vk = GainLayout<M>::Vk, VR = TargetLayout<M, false>::V;
+    // elements per step of the wave's problems, and where each array starts in the image
+    static constexpr int KE = M::NU * M::NX * PPW, kE = M::NU * PPW, UE = M::NU * PPW, RE = M::NX * PPW;
     static constexpr int oK = 0, ok = KE, oU = KE + kE, oR = KE + kE + UE, STEP = KE + kE + UE + RE;
-    static constexpr int NLD = STEP / WE;                          // loads per step
+    static constexpr int NLD = STEP / (TILE * G);                   // load instructions per step
     static constexpr int BYTES = EVAL_RING * STEP * (int)sizeof(T); // per wave
-    // whole wave instructions per array, and the rings of a workgroup's four waves within 128 KiB of LDS
-    static constexpr bool OK = M::NX <= 8 && KE % WE == 0 && kE % WE == 0 && UE % WE == 0 && RE % WE == 0 && 4 * BYTES <= 131072;
+    // whole granules per row group and whole instructions per step; the rings of the workgroups of a CU
+    // (four waves each, L of them) within 128 KiB of LDS
+    static constexpr bool OK = M::NX <= 8 && (L == 1 || L == 2) && (PPW * VK) % G == 0 && (PPW * Vk) % G == 0 && PPW % G == 0 &&
+                               (PPW * VR) % G == 0 && STEP % (TILE * G) == 0 && 4 * L * BYTES <= 131072;
+    // element offsets inside the image: K[i][j], k[i], U[i], Xref[i] of the wave's problem number pl
+    static __device__ __forceinline__ constexpr int at_K(int i, int j, int pl) { return oK + ((i * M::NX + j) / VK) * (PPW * VK) + pl * VK + (i * M::NX + j) % VK; }
+    static __device__ __forceinline__ constexpr int at_k(int i, int pl) { return ok + (i / Vk) * (PPW * Vk) + pl * Vk + i % Vk; }
+    static __device__ __forceinline__ constexpr int at_U(int i, int pl) { return oU + i * PPW + pl; }
+    static __device__ __forceinline__ constexpr int at_R(int i, int pl) { return oR + (i / VR) * (PPW * VR) + pl * VR + i % VR; }
+    // Source of granule number `gi` of a step's image: which array (0 K, 1 k, 2 U, 3 Xref), and the
+    // element offset inside that array's rows of the step for the tile (`first` = the wave's first lane)
+    static __device__ __forceinline__ void source(int gi, int first, int &arr, int &off) {
+        const int e = gi * G; // element of the image
+        int base, V;
+        if (e < ok) arr = 0, base = oK, V = VK;
+        else if (e < oU) arr = 1, base = ok, V = Vk;
+        else if (e < oR) arr = 2, base = oU, V = 1;
+        else arr = 3, base = oR, V = VR;
+        const int w = e - base, grp = w / (PPW * V), in = w % (PPW * V);
+        off = grp * (TILE * V) + first * V + in;
+    }
 };
 template <typename T> struct EvalTile { // what the LDS path needs beside the per-lane pointers
     const T *K = nullptr, *k = nullptr, *U = nullptr, *R = nullptr; // the wave's tile of each array
     unsigned char *ring = nullptr;                                   // the wave's own ring
-    int lane = 0;
+    int lane = 0, first = 0;                                         // lane; first lane of the tile this wave works on
 };
 
 template <typename T, int NX, int NU> struct FwdRow { // rows of one step shared by all step sizes of a problem
@@ -1952,7 +1977,7 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
                                                 int &best, T &best_cost, bool &bad, const T *SCp = nullptr, T *CKp = nullptr,
                                                 bool ck_store = false, EvalTile<T> et = EvalTile<T>()) {
     constexpr int NX = M::NX, NU = M::NU;
-    static_assert(!LDSR || (L == 1 && REROLL && !BARRIER && !TC && !CKPT && EvalRing<T, M>::OK), "LDS row ring: see EvalRing");
+    static_assert(!LDSR || (REROLL && !BARRIER && !TC && !CKPT && EvalRing<T, M, L>::OK), "LDS row ring: see EvalRing");
     const int T1 = p.N - 1;
     auto load_row = [&](int t, FwdRow<T, NX, NU> &r) {
 #pragma unroll
@@ -2012,34 +2037,39 @@ __device__ __forceinline__ void evaluate_rounds(const P &p, const T *Xt, const T
             }
         };
         if constexpr (LDSR) {
-            using ER = EvalRing<T, M>;
+            using ER = EvalRing<T, M, L>;
             T *const img0 = (T *)et.ring;
-            const int lane = et.lane;
+            const int pl = et.lane / L;
+            // this lane's granule of each load instruction: where it comes from at step 0, and how far
+            // that moves per step (an array's rows of a step are contiguous)
+            const T *src[ER::NLD];
+            unsigned stride[ER::NLD];
+#pragma unroll
+            for (int q = 0; q < ER::NLD; ++q) {
+                int arr, off;
+                ER::source(q * TILE + et.lane, et.first, arr, off);
+                src[q] = (arr == 0 ? et.K : arr == 1 ? et.k : arr == 2 ? et.U : et.R) + off;
+                stride[q] = (unsigned)((arr == 0 ? NU * NX : arr == 3 ? NX : NU) * TILE);
+            }
             // the rows of step t (past the end: of the last step again, so that the count of loads in
             // flight stays what the waits below assume) into ring slot `slot`
             auto issue = [&](int t, int slot) {
                 const size_t tt = (size_t)(t < T1 ? t : T1 - 1);
                 T *dst = img0 + slot * ER::STEP;
 #pragma unroll
-                for (int q = 0; q < ER::KE / ER::WE; ++q) glds16(et.K + tt * ER::KE + q * ER::WE + lane * ER::G, dst + ER::oK + q * ER::WE);
-#pragma unroll
-                for (int q = 0; q < ER::kE / ER::WE; ++q) glds16(et.k + tt * ER::kE + q * ER::WE + lane * ER::G, dst + ER::ok + q * ER::WE);
-#pragma unroll
-                for (int q = 0; q < ER::UE / ER::WE; ++q) glds16(et.U + tt * ER::UE + q * ER::WE + lane * ER::G, dst + ER::oU + q * ER::WE);
-#pragma unroll
-                for (int q = 0; q < ER::RE / ER::WE; ++q) glds16(et.R + tt * ER::RE + q * ER::WE + lane * ER::G, dst + ER::oR + q * ER::WE);
+                for (int q = 0; q < ER::NLD; ++q) glds16(src[q] + tt * stride[q], dst + q * (TILE * ER::G));
             };
             auto read_row = [&](int slot, FwdRow<T, NX, NU> &r) {
                 const T *img = img0 + slot * ER::STEP;
 #pragma unroll
                 for (int i = 0; i < NU; ++i) {
-                    r.k[i] = img[ER::ok + gain_k<M>(0, i) + lane * GainLayout<M>::Vk];
-                    r.up[i] = img[ER::oU + i * TILE + lane];
+                    r.k[i] = img[ER::at_k(i, pl)];
+                    r.up[i] = img[ER::at_U(i, pl)];
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) r.K[i][j] = img[ER::oK + gain_K<M>(i, j) + lane * GainLayout<M>::VK];
+                    for (int j = 0; j < NX; ++j) r.K[i][j] = img[ER::at_K(i, j, pl)];
                 }
 #pragma unroll
-                for (int i = 0; i < NX; ++i) r.xr[i] = img[ER::oR + target_x<M, false>(0, i) + lane * TargetLayout<M, false>::V];
+                for (int i = 0; i < NX; ++i) r.xr[i] = img[ER::at_R(i, pl)];
                 r.cx = r.cy = r.rad = r.s = r.c = T(0);
             };
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // (nothing of an earlier sweep still touches the ring)
@@ -2184,13 +2214,15 @@ __device__ __forceinline__ void evaluate_body(const P &p, int end, int wave, int
     const int nseg = (T1 + COMMIT_SEG - 1) / COMMIT_SEG;
     T *CKp = CKPT ? tile_ptr(p.CK, tile, nseg * CK_CANDIDATES * NX, ln) : nullptr;
     EvalTile<T> et;
-    if constexpr (LDSR) { // (L = 1: the wave's problems are the tile `wave`)
-        et.K = p.K + (size_t)wave * (T1 * NU * NX) * TILE;
-        et.k = p.k + (size_t)wave * (T1 * NU) * TILE;
-        et.U = p.U + (size_t)wave * (T1 * NU) * TILE;
-        et.R = p.Xref + (size_t)wave * (p.N * NX) * TILE;
+    if constexpr (LDSR) { // (the wave's problems are PPW neighbouring lanes of one tile)
+        const int wt = (wave * PPW) >> 6;
+        et.K = p.K + (size_t)wt * (T1 * NU * NX) * TILE;
+        et.k = p.k + (size_t)wt * (T1 * NU) * TILE;
+        et.U = p.U + (size_t)wt * (T1 * NU) * TILE;
+        et.R = p.Xref + (size_t)wt * (p.N * NX) * TILE;
         et.ring = ring;
         et.lane = lane;
+        et.first = (wave * PPW) & 63;
     }
     evaluate_rounds<T, M, DIAG, BARRIER, L, A, REROLL, true, TC, CKPT, LDSR>(p, Xt, Rt, Ut, Kp, kp, Cp, Dp, al, active, Jcur, 0, end, best,
                                                                               best_cost, bad, SCp, CKp, true, et);
@@ -2233,13 +2265,20 @@ __device__ __forceinline__ void evaluate_body(const P &p, int end, int wave, int
 
 template <typename T, class M, bool DIAG, bool BARRIER, int L, int A, bool REROLL, bool TC = false, bool CKPT = false, bool LDSR = false>
 __global__ __launch_bounds__(256, EVAL_MIN_WAVES) void evaluate_kernel(Params<T, M::NX, M::NU> p, int end) {
-    if constexpr (LDSR) {
-        __shared__ __attribute__((aligned(16))) unsigned char ring[4 * EvalRing<T, M>::BYTES];
-        const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        evaluate_body<T, M, DIAG, BARRIER, L, A, REROLL, TC, CKPT, true>(p, end, blockIdx.x * 4 + w, threadIdx.x & 63, ring + w * EvalRing<T, M>::BYTES);
-    } else {
-        evaluate_body<T, M, DIAG, BARRIER, L, A, REROLL, TC, CKPT>(p, end, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), threadIdx.x & 63);
-    }
+    static_assert(!LDSR, "the ring variant is evaluate_ring_kernel");
+    evaluate_body<T, M, DIAG, BARRIER, L, A, REROLL, TC, CKPT>(p, end, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
+// Stage one with the rows through LDS (EvalRing): L workgroups of four waves per CU, i.e. L waves per
+// SIMD, each within 512 / L registers.  With two lanes per problem (three step sizes each) the two
+// waves of a SIMD fill each other's stalls (dependent instructions, the LDS reads at the top of a
+// step), which a single wave per SIMD with six step sizes per lane cannot.
+template <typename T, class M, bool DIAG, int L, int A>
+__global__ __launch_bounds__(256, L) void evaluate_ring_kernel(Params<T, M::NX, M::NU> p, int end) {
+    __shared__ __attribute__((aligned(16))) unsigned char ring[4 * EvalRing<T, M, L>::BYTES];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    evaluate_body<T, M, DIAG, false, L, A, true, false, false, true>(p, end, blockIdx.x * 4 + w, threadIdx.x & 63,
+                                                                      ring + w * EvalRing<T, M, L>::BYTES);
 }
 
 // ---------------------------------------------------------------- evaluate, stage two
