@@ -473,7 +473,7 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
             if (!barrier_on(c) && c.n_alphas <= 16 && !generic) {
                 if (!(c.eval_stages & 1)) return hipSuccess;
                 auto p = make_params<T, NX, NU>(c);
-                hipLaunchKernelGGL(ltv12x4_evaluate_mfma_kernel<T>, dim3((c.count + 15) / 16), dim3(1024), 0, s, p);
+                hipLaunchKernelGGL((ltv12x4_evaluate_mfma_kernel<T, LTV_EVALUATE_PW>), dim3((c.count + 15) / 16), dim3(1024 / LTV_EVALUATE_PW), 0, s, p);
                 return hipGetLastError();
             }
         }

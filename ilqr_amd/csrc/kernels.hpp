@@ -1505,8 +1505,11 @@ constexpr int LTV_RING = 4;
 #ifndef LTV_BACKWARD_GROUP
 #define LTV_BACKWARD_GROUP 2
 #endif
+#ifndef LTV_EVALUATE_RING
+#define LTV_EVALUATE_RING 4
+#endif
 #ifndef LTV_EVALUATE_GROUP
-#define LTV_EVALUATE_GROUP 2
+#define LTV_EVALUATE_GROUP 1
 #endif
 __device__ __forceinline__ void glds16(const void *src, void *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
@@ -1532,16 +1535,62 @@ template <typename T> struct LtvStage {
 // wherever a lane stands for a row or a column of a matrix (hardware row 4 g + r then is index
 // tau(4 g + r) = g + 4 r; tau is its own inverse).
 template <typename T> struct Mfma4;
+//
+// `run4`: a product whose left factor has only four rows, M (4 x 4 per call) times a 4 x 16 right
+// factor, result row g of column c in lane (c, g).  Lane (c, g) supplies M[c % 4][k] and right[k][c],
+// k = g (every group of four lanes repeats M).  In fp64 this is the instruction that multiplies four
+// independent 4 x 4 x 4 blocks (block b = columns 4 b .. 4 b + 3; measured on gfx950: its operands and
+// result sit in exactly these lanes), a quarter of the 16 x 16 x 4 instruction's time: on this chip
+// an fp64 matrix instruction and the vector instructions of the other waves of the SIMD do not
+// overlap (tools/ubench_mfma.hip), so its 48 cycles less are 48 cycles less.  fp32 has no such
+// shape; there it is the 16 x 16 x 4 instruction, whose rows 4.. nobody reads.
 template <> struct Mfma4<double> {
     using acc = v4f64_;
+    using acc4 = double;
+    static constexpr bool HAS4 = true; // run4 is an instruction of its own
     static __device__ __forceinline__ acc run(double a, double b, acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ acc4 zero4() { return 0.0; }
+    static __device__ __forceinline__ acc4 run4(double a, double b, acc4 c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ double first(acc4 c) { return c; }
     static __device__ __forceinline__ int tau(int c) { return c; }
 };
 template <> struct Mfma4<float> {
     using acc = v4f32_;
+    using acc4 = v4f32_;
+    static constexpr bool HAS4 = false;
     static __device__ __forceinline__ acc run(float a, float b, acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ acc4 zero4() { return acc4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    static __device__ __forceinline__ acc4 run4(float a, float b, acc4 c) { return run(a, b, c); }
+    static __device__ __forceinline__ float first(acc4 c) { return c[0]; }
     static __device__ __forceinline__ int tau(int c) { return (c >> 2) + 4 * (c & 3); }
 };
+
+// x + (x of the lane 16 / 32 away), without the LDS crossbar: the swap instructions of gfx950 exchange
+// the odd rows (16 lanes) resp. the upper half of one register with the even rows resp. the lower half
+// of another, so that two copies of x become "x of the even partner" and "x of the odd partner" in
+// every lane.  The sum is the one `x + __shfl_xor(x, 16)` gives, bit for bit (addition commutes).
+__device__ __forceinline__ double add_across16(double x) {
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double add_across32(double x) {
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ float add_across16(float x) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+__device__ __forceinline__ float add_across32(float x) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+// the sum over the four lane groups of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48), in every lane
+template <typename T> __device__ __forceinline__ T add_lane_groups(T x) { return add_across32(add_across16(x)); }
 
 // Backward sweep of the n = 12, m = 4 model for 16 neighbouring problems of a tile at once: 16
 // waves, one problem each (the arithmetic of ltv12x4_backward_sweep with the branch-free solve),
@@ -1562,7 +1611,7 @@ template <typename T, bool BOXQP = false> __global__ __launch_bounds__(1024) voi
     constexpr int IN_ROWS = 28, OUT_ROWS = 52, AGR = NX * NX * ES / 16, TBL = NX * (NX + NU) * ES / 16;
     constexpr int NLOAD = (IN_ROWS * GPR + TBL + 63) / 64, NSTORE = (OUT_ROWS * GPR + 63) / 64; // waves that load / that store
     constexpr int IN_BYTES = NLOAD * 1024, OUT_BYTES = NSTORE * 1024;
-    constexpr int SHW = 24; // words of a wave's own LDS: Quu (16), the step's inputs (4, BOXQP)
+    constexpr int SHW = 40, SH_VX = 24; // words of a wave's own LDS: Quu (16), the step's inputs (4, BOXQP), .., Vx (16)
     constexpr int OFF_OUT = D * S * IN_BYTES, OFF_SH = OFF_OUT + 2 * S * OUT_BYTES, OFF_FLAG = OFF_SH + 16 * SHW * ES;
     static_assert(NLOAD + NSTORE <= 16 && D % 2 == 0, "wave roles, image parity");
     __shared__ __attribute__((aligned(16))) unsigned char lds[OFF_FLAG + 64];
@@ -1662,23 +1711,32 @@ template <typename T, bool BOXQP = false> __global__ __launch_bounds__(1024) voi
 #pragma unroll
         for (int q = 1; q < 4; ++q) oq[(r - 1) * 3 + q] = ((g + r) & 3) * 4 + (((ci & 3) + q) & 3);
     const T csign = ((ci + g) & 1) ? T(-1) : T(1);
-    bool bad = false;
+    bool good = true;
+    const bool is12 = ci == NX;
     auto one_step = [&](const unsigned char *img, unsigned char *out) {
         const T xu_c = *(const T *)(img + oxu), xr_raw = *(const T *)(img + oxr);
         const T F0 = *(const T *)(img + oF), F1 = *(const T *)(img + oF + oFk), F2 = *(const T *)(img + oF + 2 * oFk); // F[g + 4 kk][ci]
         const T xr_c = isx ? xr_raw : T(0);
         // first-order terms: [Qx; Qu] = [lx; lu] + F' Vx (ilqr.py:93-94)
-        T part = F0 * __shfl(vx, MF::tau(g)) + F1 * __shfl(vx, MF::tau(g + 4)) + F2 * __shfl(vx, MF::tau(g + 8));
-        part += __shfl_xor(part, 16);
-        part += __shfl_xor(part, 32);
-        const T qv = fma_(lw, xu_c - xr_c, part);
+        // (Vx[i] travels through the wave's own LDS words, at (i % 4) 4 + i / 4, so that the three
+        // components g, g + 4, g + 8 a lane multiplies are neighbours: a write and two reads instead of
+        // six crossbar instructions)
+        if (g == 0) sh[SH_VX + (ci & 3) * 4 + (ci >> 2)] = vx;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const T vx0 = sh[SH_VX + g * 4], vx1 = sh[SH_VX + g * 4 + 1], vx2 = sh[SH_VX + g * 4 + 2];
         // W = (Vxx + lm I) F, then G = F' W with register r of lane (ci, g) = G[ci][g + 4 r] (layouts:
         // see ltv12x4_backward_sweep).  Lanes that stand for an input hold rows 12..15 of the left
-        // factor of W, which only produce rows that no later product reads: no masking needed.
+        // factor of W, which only produce rows that no later product reads; row 12 is put to use: with
+        // Vx' as that row, row 12 of W is Vx' F = (F' Vx)', the first-order product, for nothing
+        // (register 3 of the lanes g = 0; a matrix instruction costs the SIMD the same 64 cycles
+        // whatever its padding rows hold, and a sum over the lane groups costs ten more instructions).
         acc W = {T(0), T(0), T(0), T(0)};
-        W = MF::run(Vt[0] + lmd[0], F0, W);
-        W = MF::run(Vt[1] + lmd[1], F1, W);
-        W = MF::run(Vt[2] + lmd[2], F2, W);
+        W = MF::run(is12 ? vx0 : Vt[0] + lmd[0], F0, W);
+        W = MF::run(is12 ? vx1 : Vt[1] + lmd[1], F1, W);
+        W = MF::run(is12 ? vx2 : Vt[2] + lmd[2], F2, W);
+        const T qv = fma_(lw, xu_c - xr_c, W[3]); // (lanes g = 0)
         acc TG = {T(0), T(0), T(0), T(0)};
         TG = MF::run(W[0], F0, TG);
         TG = MF::run(W[1], F1, TG);
@@ -1698,7 +1756,7 @@ template <typename T, bool BOXQP = false> __global__ __launch_bounds__(1024) voi
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         T cof = T(0), a_ij = T(0);
         bool pd = true;
-        if (ci < NU) {
+        { // (every lane: lane (c, g) computes entry (c % 4, g), which is what run4 wants from it)
             const T b11 = sh[oq[1]], b12 = sh[oq[2]], b13 = sh[oq[3]], b21 = sh[oq[4]], b22 = sh[oq[5]], b23 = sh[oq[6]], b31 = sh[oq[7]],
                     b32 = sh[oq[8]], b33 = sh[oq[9]];
             a_ij = sh[oq[0]];
@@ -1711,20 +1769,16 @@ template <typename T, bool BOXQP = false> __global__ __launch_bounds__(1024) voi
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        T det = a_ij * cof;
-        det += __shfl_xor(det, 16);
-        det += __shfl_xor(det, 32);
-        bad = bad || __ballot(lane == 0 && !(pd && det > T(0))) != 0ull;
-        const T inv_e = cof * fast_rcp(det); // (Quu^-1)[ci][g] in the lanes ci < 4
+        const T det = add_lane_groups(a_ij * cof);
+        good = good && pd && det > T(0); // (lane 0's is the one that counts)
+        const T inv_e = cof * fast_rcp(det); // (Quu^-1)[ci % 4][g]
         // [K | k] = -Quu^-1 [Qux | Qu] as one more product: this lane supplies entry (g, ci) of the
         // right factor, Qux[g][ci] (state lanes; taken from G[ci][12 + g], which this lane holds: G is
         // symmetric up to the rounding of Vxx) or Qu[g] (the lane of index 12), and gets row g of
         // column ci of the result in register 0.
         const T qug = __shfl(qv, MF::tau(NX + g)); // Qu[g]
         const T qg = TG[3];
-        acc R = {T(0), T(0), T(0), T(0)};
-        R = MF::run(inv_e, ci == NX ? qug : qg, R);
-        T kg = -R[0]; // K[g][ci] (ci < 12), k[g] (ci == 12)
+        T kg = -MF::first(MF::run4(inv_e, ci == NX ? qug : qg, MF::zero4())); // K[g][ci] (ci < 12), k[g] (ci == 12)
         if (BOXQP) {
             T uj[NU], gg = T(2) * qug;
 #pragma unroll
@@ -1748,12 +1802,11 @@ template <typename T, bool BOXQP = false> __global__ __launch_bounds__(1024) voi
             }
         }
         if (gain_on) *(T *)(out + ogain) = kg;
-        // Vx = Qx + K' Qu ; Vxx = Qxx + K' Qux (ilqr.py:104-105)
-        T kq = kg * qug;
-        kq += __shfl_xor(kq, 16);
-        kq += __shfl_xor(kq, 32);
-        vx = qv + kq; // (the lanes of the inputs are never asked for theirs)
-        TG = MF::run(qg, kg, TG);
+        // Vx = Qx + K' Qu ; Vxx = Qxx + K' Qux (ilqr.py:104-105): one product, with Qu' as row 12 of the
+        // left factor Qux' (and the rows 12.. of the sum, which have served, cleared)
+        TG[3] = T(0);
+        TG = MF::run(is12 ? qug : qg, kg, TG);
+        vx = qv + TG[3]; // (lanes g = 0 of the states; nobody asks the others for theirs)
 #pragma unroll
         for (int r = 0; r < 3; ++r) Vt[r] = TG[r];
     };
@@ -1802,7 +1855,7 @@ template <typename T, bool BOXQP = false> __global__ __launch_bounds__(1024) voi
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     write_group(NM - 1);
-    if (act && lane == 0) p.redo[o] = bad ? 1 : 0;
+    if (act && lane == 0) p.redo[o] = good ? 0 : 1;
 }
 
 // The fallback launch behind ltv12x4_backward_staged_kernel (normally idle): the problems it flagged
@@ -1874,7 +1927,10 @@ __device__ __forceinline__ void control_update(const P &p, T alpha, const T (&x)
 // the same rows cost 32 VGPRs per step in flight, and with the six candidates' states a second step
 // in flight no longer fits: the compiler then issues the loads late in the step before, and the wave
 // waits for memory in a sixth of its cycles.
-constexpr int EVAL_RING = 4;
+#ifndef ILQR_EVAL_RING
+#define ILQR_EVAL_RING 4
+#endif
+constexpr int EVAL_RING = ILQR_EVAL_RING;
 // (L lanes per problem: a wave works on the 64 / L problems of a part of a tile, whose values of a row
 // group are PPW * V contiguous elements; a load instruction gathers 64 granules of 16 bytes, one per
 // lane, from wherever they are, and LDS receives them in lane order: the step's image in LDS is the
@@ -1891,7 +1947,7 @@ template <typename T, class M, int L> struct EvalRing {
     // whole granules per row group and whole instructions per step; the rings of the workgroups of a CU
     // (four waves each, L of them) within 128 KiB of LDS
     static constexpr bool OK = M::NX <= 8 && (L == 1 || L == 2) && (PPW * VK) % G == 0 && (PPW * Vk) % G == 0 && PPW % G == 0 &&
-                               (PPW * VR) % G == 0 && STEP % (TILE * G) == 0 && 4 * L * BYTES <= 131072;
+                               (PPW * VR) % G == 0 && STEP % (TILE * G) == 0 && 4 * L * BYTES <= (EVAL_RING > 4 ? 163840 : 131072);
     // element offsets inside the image: K[i][j], k[i], U[i], Xref[i] of the wave's problem number pl
     static __device__ __forceinline__ constexpr int at_K(int i, int j, int pl) { return oK + ((i * M::NX + j) / VK) * (PPW * VK) + pl * VK + (i * M::NX + j) % VK; }
     static __device__ __forceinline__ constexpr int at_k(int i, int pl) { return ok + (i / Vk) * (PPW * Vk) + pl * Vk + i % Vk; }
@@ -2619,24 +2675,42 @@ __global__ __launch_bounds__(64) void evaluate_listed_kernel(Params<T, M::NX, M:
 // load writes lane i of a wave at base + 16 i), rotated within each row (LtvStage): a wave reads
 // the same problem of 16 different rows in one instruction, and the rotation puts those 16 on 16
 // different bank groups.
-template <typename T> __global__ __launch_bounds__(1024) void ltv12x4_evaluate_mfma_kernel(Params<T, 12, 4> p) {
+//
+// PW problems per wave (workgroup = 16 / PW waves): the chains of a wave's problems are independent,
+// so the instructions of one fill the waits of the other (a matrix instruction's result is ready 4
+// to 16 passes after it issues; with one problem per wave and four waves per SIMD the SIMD sat idle
+// a third of the time).  The problems of a wave are neighbours inside one 16-byte granule of every
+// row, so one set of addresses serves them.
+#ifndef LTV_EVALUATE_PW
+#define LTV_EVALUATE_PW 2
+#endif
+template <typename T, int PW = LTV_EVALUATE_PW> __global__ __launch_bounds__(1024 / PW, 4) void ltv12x4_evaluate_mfma_kernel(Params<T, 12, 4> p) {
     using St = LtvStage<T>;
     using MF = Mfma4<T>;
     using acc = typename MF::acc;
-    constexpr int NX = 12, NU = 4, D = LTV_RING, S = LTV_EVALUATE_GROUP, ES = (int)sizeof(T), GPR = St::GPR, PPG = St::PPG;
+    constexpr int NX = 12, NU = 4, D = LTV_EVALUATE_RING, S = LTV_EVALUATE_GROUP, ES = (int)sizeof(T), GPR = St::GPR, PPG = St::PPG;
     constexpr int ROWS = 80; // rows of a step: K 0..47, k 48..51, x 52..63, u 64..67, xref 68..79
     constexpr int AGR = NX * NX * ES / 16, TBL = NX * (NX + NU) * ES / 16;
     constexpr int NLOAD = (ROWS * GPR + TBL + 63) / 64, CHUNK = NLOAD * 1024;
+    constexpr int NW = 16 / PW, LPW = (NLOAD + NW - 1) / NW; // waves; load instructions per step of a wave (the first waves: LPW, the others LPW - 1)
+    static_assert(PPG % PW == 0 && 16 % PW == 0, "a wave's problems share a granule");
     __shared__ __attribute__((aligned(16))) unsigned char ring[D * S * CHUNK];
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const int ci = MF::tau(c);                                      // the row of a left factor this lane supplies
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave = problem of the workgroup
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave: problems PW w .. PW w + PW - 1 of the workgroup
     const int nsl = slot_count(p);
-    const int slot0 = blockIdx.x * 16, slot_raw = slot0 + w;
-    const int slot = slot_raw < nsl ? slot_raw : (nsl > 0 ? nsl - 1 : 0);
-    const int o = orig_of(p, slot);
-    const bool act = slot_raw < nsl && p.converged[o] == 0;
-    if (!__syncthreads_or(act)) return; // no wave of this workgroup has work
+    const int slot0 = blockIdx.x * 16;
+    int o[PW];
+    bool act[PW], any = false;
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+        const int slot_raw = slot0 + PW * w + j;
+        const int slot = slot_raw < nsl ? slot_raw : (nsl > 0 ? nsl - 1 : 0);
+        o[j] = orig_of(p, slot);
+        act[j] = slot_raw < nsl && p.converged[o[j]] == 0;
+        any = any || act[j];
+    }
+    if (!__syncthreads_or(any)) return; // no wave of this workgroup has work
     const int T1 = p.N - 1;
     const int tile = slot0 >> 6, ln0 = slot0 & 63; // the workgroup's 16 problems: lanes ln0 .. ln0 + 15 of one tile
     const T *Xt = tile_ptr(p.X, tile, p.N * NX, ln0);
@@ -2650,15 +2724,21 @@ template <typename T> __global__ __launch_bounds__(1024) void ltv12x4_evaluate_m
     }
     const T rw = p.R[g * NU + g], lo = p.lo[g], hi = p.hi[g];
     // candidates start from the stored first state
-    T z[4], cost = T(0);
+    T z[PW][4], cost[PW];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) z[r] = Xt[(size_t)(g + 4 * r) * TILE + w];
-    z[3] = T(0);
-    // this lane's granule of every step: source address at step 0 and its stride per step
-    const unsigned char *src;
-    unsigned stride;
-    {
-        const int q = threadIdx.x, row = q / GPR;
+    for (int j = 0; j < PW; ++j) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) z[j][r] = Xt[(size_t)(g + 4 * r) * TILE + PW * w + j];
+        z[j][3] = T(0);
+        cost[j] = T(0);
+    }
+    // this lane's granules of every step (load instruction number w + i NW of the step): source
+    // address at step 0 and stride per step
+    const unsigned char *src[LPW];
+    unsigned stride[LPW];
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        const int q = (w + i * NW) * 64 + lane, row = q / GPR;
         if (q < ROWS * GPR) {
             const T *b;
             int r, rows;
@@ -2667,57 +2747,93 @@ template <typename T> __global__ __launch_bounds__(1024) void ltv12x4_evaluate_m
             else if (row < 64) b = Xt, r = row - 52, rows = NX;
             else if (row < 68) b = tile_ptr(p.U, tile, T1 * NU, ln0), r = row - 64, rows = NU;
             else b = Rt, r = row - 68, rows = NX;
-            src = (const unsigned char *)(b + (size_t)r * TILE + St::first_problem(q));
-            stride = (unsigned)(rows * TILE * ES);
+            src[i] = (const unsigned char *)(b + (size_t)r * TILE + St::first_problem(q));
+            stride[i] = (unsigned)(rows * TILE * ES);
         } else {
             const int e = q - ROWS * GPR < TBL ? q - ROWS * GPR : TBL - 1; // (padding lanes repeat the last granule)
-            src = (const unsigned char *)(e < AGR ? p.ltvA + PPG * e : p.ltvB + PPG * (e - AGR));
-            stride = (unsigned)((e < AGR ? NX * NX : NX * NU) * ES);
+            src[i] = (const unsigned char *)(e < AGR ? p.ltvA + PPG * e : p.ltvB + PPG * (e - AGR));
+            stride[i] = (unsigned)((e < AGR ? NX * NX : NX * NU) * ES);
         }
     }
     auto stage = [&](int t, int buf) {
-        if (w < NLOAD) glds16(src + (size_t)t * stride, ring + buf * CHUNK + w * 1024);
+#pragma unroll
+        for (int i = 0; i < LPW; ++i)
+            if (w + i * NW < NLOAD) glds16(src[i] + (size_t)t * stride[i], ring + buf * CHUNK + (w + i * NW) * 1024);
     };
-    // where this lane's operands sit in a step's image.  The matrix instruction's left operand of a
-    // lane is one row of the left factor: rows >= 4 of K and rows >= 12 of [A_t | B_t] only produce
-    // result rows nobody reads, so those lanes simply read a valid row.
+    const bool full_loader = w + (LPW - 1) * NW < NLOAD; // this wave issues LPW loads per step (else LPW - 1)
+    // where this lane's operands sit in a step's image (first problem of the wave; the next ones
+    // follow at the element size).  The matrix instruction's left operand of a lane is one row of
+    // the left factor: rows >= 4 of K and rows >= 12 of [A_t | B_t] only produce result rows nobody
+    // reads, so those lanes simply read a valid row.
     unsigned oxp[3], oxr[3], oK[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-        oxp[q] = St::off(52 + g + 4 * q, w);
-        oxr[q] = St::off(68 + g + 4 * q, w);
-        oK[q] = St::off((ci & 3) * NX + g + 4 * q, w);
+        oxp[q] = St::off(52 + g + 4 * q, PW * w);
+        oxr[q] = St::off(68 + g + 4 * q, PW * w);
+        oK[q] = St::off((ci & 3) * NX + g + 4 * q, PW * w);
     }
-    const unsigned oup = St::off(64 + g, w), okf = St::off(48 + g, w);
+    const unsigned oup = St::off(64 + g, PW * w), okf = St::off(48 + g, PW * w);
     const int cc = ci < NX ? ci : 0;
     const unsigned oA = ROWS * GPR * 16 + (cc * NX + g) * ES, oB = ROWS * GPR * 16 + NX * NX * ES + (cc * NU + g) * ES;
+    const unsigned oA4 = ROWS * GPR * 16 + ((c & 3) * NX + g) * ES, oB4 = ROWS * GPR * 16 + NX * NX * ES + ((c & 3) * NU + g) * ES;
     auto one_step = [&](const unsigned char *img) {
         auto at = [&](unsigned off) { return *(const T *)(img + off); };
-        T dx[3], e[3];
+        // the table operands are the same for the wave's problems
+        T FA[MF::HAS4 ? 12 : 4];
+        if constexpr (MF::HAS4) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            dx[q] = z[q] - at(oxp[q]);
-            e[q] = z[q] - at(oxr[q]);
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) FA[r * 4 + kk] = at(oA4 + (4 * r * NX + 4 * kk) * ES);
+                FA[r * 4 + 3] = at(oB4 + 4 * r * NU * ES);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) FA[q] = at(oA + 4 * ES * q);
+            FA[3] = at(oB);
         }
-        acc KD = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-        for (int q = 0; q < 3; ++q) KD = MF::run(at(oK[q]), dx[q], KD);
-        // u_new = (u_prev + alpha k) + K (x_new - x_prev), clamped (ilqr.py:56-61)
-        T v = fma_(alpha, at(okf), at(oup)) + KD[0];
-        v = (lo > v) ? lo : v;
-        v = (hi < v) ? hi : v;
-        z[3] = v;
-        T stage_cost = (qw[0] * e[0]) * e[0];
-        stage_cost = fma_(qw[1] * e[1], e[1], stage_cost);
-        stage_cost = fma_(qw[2] * e[2], e[2], stage_cost);
-        stage_cost = fma_(rw * v, v, stage_cost);
-        cost += stage_cost;
-        acc Xn = {T(0), T(0), T(0), T(0)};
+        for (int j = 0; j < PW; ++j) {
+            T dx[3], e[3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) Xn = MF::run(at(oA + 4 * ES * q), z[q], Xn);
-        Xn = MF::run(at(oB), z[3], Xn);
+            for (int q = 0; q < 3; ++q) {
+                dx[q] = z[j][q] - at(oxp[q] + j * ES);
+                e[q] = z[j][q] - at(oxr[q] + j * ES);
+            }
+            typename MF::acc4 KD = MF::zero4();
 #pragma unroll
-        for (int q = 0; q < 3; ++q) z[q] = Xn[q];
+            for (int q = 0; q < 3; ++q) KD = MF::run4(at(oK[q] + j * ES), dx[q], KD);
+            // u_new = (u_prev + alpha k) + K (x_new - x_prev), clamped (ilqr.py:56-61)
+            T v = fma_(alpha, at(okf + j * ES), at(oup + j * ES)) + MF::first(KD);
+            v = (lo > v) ? lo : v;
+            v = (hi < v) ? hi : v;
+            z[j][3] = v;
+            T stage_cost = (qw[0] * e[0]) * e[0];
+            stage_cost = fma_(qw[1] * e[1], e[1], stage_cost);
+            stage_cost = fma_(qw[2] * e[2], e[2], stage_cost);
+            stage_cost = fma_(rw * v, v, stage_cost);
+            cost[j] += stage_cost;
+            if constexpr (MF::HAS4) {
+                // X+ = [A_t | B_t] Z by four-row products: rows g, g + 4, g + 8 of the result are three
+                // chains of four calls (12 x 16 cycles instead of 4 x 64: the 16-row form computes four rows
+                // nobody reads).  Left operand of lane (c, g) for rows r, step kk: F[c % 4 + 4 r][g + 4 kk].
+                typename MF::acc4 xn[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    xn[r] = MF::zero4();
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) xn[r] = MF::run4(FA[r * 4 + kk], z[j][kk], xn[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) z[j][r] = MF::first(xn[r]);
+            } else {
+                acc Xn = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Xn = MF::run(FA[q], z[j][q], Xn);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) z[j][q] = Xn[q];
+            }
+        }
     };
     // The steps move through the ring in groups of S: group m (steps m S .. m S + S - 1) is computed
     // from ring slot m mod D while the groups m + 1 .. m + D - 1 are on their way.  A direct load is
@@ -2740,10 +2856,11 @@ template <typename T> __global__ __launch_bounds__(1024) void ltv12x4_evaluate_m
         for (int s = 0; s < D; ++s) {
             const int m = mb + s;
             if (m >= NM) break; // uniform over the workgroup
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * S) : "memory");
+            if (full_loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * S * LPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * S * (LPW - 1)) : "memory");
             __builtin_amdgcn_s_barrier();
             stage_group(m + D - 1, (s + D - 1) % D);
-            if (act) {
+            if (any) {
 #pragma unroll
                 for (int u = 0; u < S; ++u) {
                     if (m * S + u >= T1) break;
@@ -2753,26 +2870,29 @@ template <typename T> __global__ __launch_bounds__(1024) void ltv12x4_evaluate_m
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    {   // terminal term (ilqr.py:44-45)
-        T term = T(0);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const T e = z[q] - Rt[(size_t)(T1 * NX + g + 4 * q) * TILE + w];
-            term = fma_(qfw[q] * e, e, term);
+    for (int j = 0; j < PW; ++j) {
+        T cj = cost[j];
+        {   // terminal term (ilqr.py:44-45)
+            T term = T(0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const T e = z[j][q] - Rt[(size_t)(T1 * NX + g + 4 * q) * TILE + PW * w + j];
+                term = fma_(qfw[q] * e, e, term);
+            }
+            cj += term;
         }
-        cost += term;
-    }
-    const T Jcur = p.J[o];
-    cost += __shfl_xor(cost, 16);
-    cost += __shfl_xor(cost, 32);
-    // lowest step index whose cost improves strictly (ilqr.py:65; NaN never passes)
-    const unsigned long long win = __ballot(g == 0 && c < p.n_alphas && cost < Jcur);
-    const int best = win ? __ffsll((long long)win) - 1 : -1;
-    const T best_cost = __shfl(cost, best < 0 ? 0 : best);
-    if (act && lane == 0) {
-        p.alpha_idx[o] = best;
-        p.Jtry[o] = best < 0 ? T(0) : best_cost;
-        p.slow_trig[o] = p.slow_trig[o] & 6;
+        const T Jcur = p.J[o[j]];
+        cj = add_lane_groups(cj);
+        // lowest step index whose cost improves strictly (ilqr.py:65; NaN never passes)
+        const unsigned long long win = __ballot(g == 0 && c < p.n_alphas && cj < Jcur);
+        const int best = win ? __ffsll((long long)win) - 1 : -1;
+        const T best_cost = __shfl(cj, best < 0 ? 0 : best);
+        if (act[j] && lane == 0) {
+            p.alpha_idx[o[j]] = best;
+            p.Jtry[o[j]] = best < 0 ? T(0) : best_cost;
+            p.slow_trig[o[j]] = p.slow_trig[o[j]] & 6;
+        }
     }
 }
 
