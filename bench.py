@@ -281,6 +281,12 @@ def main():
                 # instruction; tools/pmc_limits.py), null without a profile of the current kernel source
                 "limiter": limit["limiter"] if limit else None,
                 "valu_busy": limit["valu_busy"] if limit else None,
+                # measured HBM bytes per launch / this run's average launch duration: the rate the memory
+                # system actually ran at (converged problems inside live tiles and whole-line fetches of
+                # scattered rows make it higher than `achieved`)
+                "traffic_GBs": (traffic / (kernels[dominant]["avg_ms"] * 1e-3) / 1e9) if traffic else None,
+                "traffic_GBs_by_kernel": ({k: traffic_all[k]["bytes_per_launch"] / (v["avg_ms"] * 1e-3) / 1e9
+                                           for k, v in kernels.items() if k in traffic_all and v["avg_ms"] > 0} if traffic_all else None),
                 "hbm_frac_by_kernel": {k: v["achieved_GBs"] / HBM_PEAK_GBS for k, v in kernels.items()},
                 "limiter_by_kernel": ({k: limits_all[k]["limiter"] for k in kernels if k in limits_all} if limits_all else None),
             },

@@ -29,7 +29,7 @@ def source_stamp():
     data = open(os.path.join(ROOT, "ilqr_amd", "csrc", "kernels.hpp"), "rb").read()
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
-NAMES = (("repack_retire_kernel", "retire"), ("backward_kernel", "backward"), ("backward_gen_kernel", "backward"), ("states_kernel", "states"), ("repack_move_kernel", "repack"), ("evaluate_listed_kernel", "evaluate_rest"), ("evaluate_kernel", "evaluate_first"),
+NAMES = (("repack_retire_kernel", "retire"), ("backward_kernel", "backward"), ("backward_gen_kernel", "backward"), ("states_kernel", "states"), ("repack_move_kernel", "repack"), ("evaluate_listed_kernel", "evaluate_rest"), ("evaluate_kernel", "evaluate_first"), ("evaluate_ring_kernel", "evaluate_first"),
          ("commit_kernel", "commit"), ("cost_kernel", "cost"), ("relayout_kernel", "relayout"))
 
 
