@@ -279,7 +279,7 @@ def main():
                 "bytes_per_problem_per_launch": ab[dominant],
                 # what the counters say the kernel is bound by (share of its wave cycles that issue a vector
                 # instruction; tools/pmc_limits.py), null without a profile of the current kernel source
-                "limiter": limit["limiter"] if limit else None,
+                "limiter": limiter_of(limit, traffic, kernels[dominant]["avg_ms"]),
                 "valu_busy": limit["valu_busy"] if limit else None,
                 # measured HBM bytes per launch / this run's average launch duration: the rate the memory
                 # system actually ran at (converged problems inside live tiles and whole-line fetches of
@@ -303,6 +303,18 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def limiter_of(limit, traffic, avg_ms):
+    """What the dominant kernel is bound by: the counters' verdict on vector issue (tools/pmc_limits.py) and,
+    beside it, the memory system when the measured traffic moves at 55 % of the HBM peak or more (the
+    read/write mixes of these kernels top out at 4.9 to 6.1 TB/s on this chip)."""
+    if not limit:
+        return None
+    rate = traffic / (avg_ms * 1e-3) / 1e9 if traffic and avg_ms > 0 else 0.0
+    if limit["limiter"] != "HBM bandwidth" and rate >= 0.55 * HBM_PEAK_GBS:
+        return limit["limiter"] + " and HBM bandwidth"
+    return limit["limiter"]
 
 
 def bench_shard(batch, rank, world, weak):
