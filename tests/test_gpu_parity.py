@@ -955,18 +955,7 @@ def test_subclass_with_own_dynamics_is_not_solved_with_the_builtin_kernels(ilqr_
     calls the overridden methods, ilqr.py:62, :87-88): the numpy methods are recorded and compiled."""
     from ilqr_amd import problems, systems
 
-    class DraggedCar(systems.Car):
-        drag = 0.05
-
-        def model_f(self, x, u):
-            xn = np.array(systems.Car.model_f(self, x, u), dtype=object if x.dtype == object else float)
-            xn[2] = xn[2] - self.drag * x[2] * self.dt
-            return xn
-
-        def compute_df_dx(self, x, u):
-            J = np.array(systems.Car.compute_df_dx(self, x, u), dtype=object if x.dtype == object else float)
-            J[2, 2] = J[2, 2] - self.drag * self.dt
-            return J
+    from helper_models import DraggedCar
 
     p = problems.car_batch(3, 50)
     outs = {}
