@@ -2,7 +2,7 @@
 """Whole-solve timings of the secondary workloads (the ones bench.py does not quote): one JSON
 line per configuration, inputs resident in HBM, time = ilqr_solve on the device, median of reps.
 
-    python tools/bench_configs.py [--reps 3] [--only car4096,car8192,car16384,car32768,cilqr16384,car65536_f32,ltv_f64,ltv_f32,cilqr_ltv_f64,cilqr_ltv_f32,sqp16384,sqp65536]
+    python tools/bench_configs.py [--reps 3] [--only car4096,car8192,car16384,car32768,cilqr16384,car65536_f32,ltv_f64,ltv_f32,ltv_f64_2s,ltv_f32_2s,cilqr_ltv_f64,cilqr_ltv_f32,sqp16384,sqp65536]
 
 car8192 / car16384 / car32768 are the per-GPU shards of the 65536-problem headline batch on 8 / 4 / 2 GPUs.
 """
@@ -49,16 +49,20 @@ def build(name):
         opt.inputs, opt.states = p["init_inputs"], p["init_states"]
         opt.set_barrier(con, mu=50.0, delta=0.5)
         return opt, "cilqr: Car, box QP + relaxed log barrier (bubbles, speed box), B=16384, N=200, maxIter=100, 8 step sizes, fp64"
-    if name in ("ltv_f64", "ltv_f32"):
+    if name in ("ltv_f64", "ltv_f32", "ltv_f64_2s", "ltv_f32_2s"):
         B, N = 32768, 500
         A, Bm, Q, R = problems.ltv_system(N=N)
         s = systems.LTVSystem(A, Bm, dt=0.05)
         s.set_cost(Q, R)
         s.set_control_limit([-2.0] * 4, [2.0] * 4)
         p = problems.ltv_batch(B, N)
-        opt = iterative_LQR(s, p["target_states"], 0.05, dtype=np.float32 if name.endswith("f32") else np.float64)
+        # "_2s": two halves of the batch on two streams (ilqr_desc.n_streams): the commit, bound by bandwidth, overlaps
+        # a little with the other half's backward pass and line search, bound by the matrix and vector units
+        # (fp64 74.8 -> 72.6 ms; nothing in fp32)
+        ns = 2 if name.endswith("_2s") else 1
+        opt = iterative_LQR(s, p["target_states"], 0.05, dtype=np.float32 if "f32" in name else np.float64, n_streams=ns)
         opt.inputs, opt.states = p["init_inputs"], p["init_states"]
-        return opt, f"LTV n=12 m=4, B={B}, N={N}, maxIter=30, {'fp32' if name.endswith('f32') else 'fp64'}"
+        return opt, f"LTV n=12 m=4, B={B}, N={N}, maxIter=30, {'fp32' if 'f32' in name else 'fp64'}, n_streams={ns}"
     if name in ("cilqr_ltv_f64", "cilqr_ltv_f32"):
         # cilqr.py:87-139 (box QP in the backward pass, 8 step sizes, maxIter 100) on the table model
         B, N = 32768, 500
