@@ -375,7 +375,9 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
             }
         }
         // one lane per problem: the rows travel through a ring in LDS (EvalRing), several steps ahead
-        if constexpr ((L == 1 || L == 2) && REROLL && !BARRIER && EvalRing<T, M, L>::OK) {
+        // (two lanes per problem share a SIMD with a second wave, i.e. 256 registers: enough for up to four
+        // step sizes per lane)
+        if constexpr ((L == 1 || (L == 2 && A <= 4)) && REROLL && !BARRIER && EvalRing<T, M, L>::OK) {
             static const bool no_ring = getenv("ILQR_NO_LDS_RING") != nullptr;
             if (!no_ring) {
                 hipLaunchKernelGGL((evaluate_ring_kernel<T, M, DIAG, L, A>), dim3(blocks), dim3(256), 0, s, p, first_end);

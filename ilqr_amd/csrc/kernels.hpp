@@ -3145,10 +3145,13 @@ template <typename T> __global__ __launch_bounds__(256) void ltv12x4_commit_mfma
     struct Row {
         T xp[3], K[NU][3], up, kf, F[4];
     };
-    auto load_row = [&](int t, Row &r) {
+    // (row t of the gains, inputs and tables, t <= T1 - 1; of the states row min(t, T1), so that the
+    // row after the last step's is the final state)
+    auto load_row = [&](int tt, Row &r) {
+        const int t = tt < T1 ? tt : T1 - 1;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            r.xp[q] = Xt[(size_t)(t * NX + g + 4 * q) * TILE];
+            r.xp[q] = Xt[(size_t)((tt < T1 ? tt : T1) * NX + g + 4 * q) * TILE];
             r.F[q] = Ap[(size_t)t * (NX * NX) + 4 * q];
 #pragma unroll
             for (int i = 0; i < NU; ++i) r.K[i][q] = Kp[(size_t)((t * NU + i) * NX + g + 4 * q) * TILE];
@@ -3157,25 +3160,22 @@ template <typename T> __global__ __launch_bounds__(256) void ltv12x4_commit_mfma
         r.up = Ut[(size_t)(t * NU + g) * TILE];
         r.kf = kp[(size_t)(t * NU + g) * TILE];
     };
-    T x[3], xlast[3];
+    T x[3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        x[q] = Xt[(size_t)(g + 4 * q) * TILE];
-        xlast[q] = Xt[(size_t)(T1 * NX + g + 4 * q) * TILE];
-    }
+    for (int q = 0; q < 3; ++q) x[q] = Xt[(size_t)(g + 4 * q) * TILE];
     // every row is read before any store reaches it: the ring holds rows t .. t+PF-1 while step t
     // writes the inputs of row t and the states of row t+1
     Row ring[PF];
 #pragma unroll
-    for (int s = 0; s < PF; ++s) load_row(s < T1 ? s : T1 - 1, ring[s]);
+    for (int s = 0; s < PF; ++s) load_row(s, ring[s]);
     for (int tb = 0; tb < T1; tb += PF) {
 #pragma unroll
         for (int sl = 0; sl < PF; ++sl) {
             const int t = tb + sl;
             if (t >= T1) break;
             const Row r = ring[sl];
-            load_row(t + PF < T1 ? t + PF : T1 - 1, ring[sl]);
-            const Row &nxt = ring[(sl + 1) % PF]; // row t+1 (if there is one)
+            load_row(t + PF, ring[sl]);
+            const Row &nxt = ring[(sl + 1) % PF]; // row t+1 (its states are the final state after the last step)
             // u_new = (u_prev + alpha k) + K (x_new - x_prev), clamped (ilqr.py:56-61)
             T dx[3], fb[NU];
 #pragma unroll
@@ -3199,7 +3199,7 @@ template <typename T> __global__ __launch_bounds__(256) void ltv12x4_commit_mfma
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 x[q] = Xn[q];
-                Xt[(size_t)((t + 1) * NX + g + 4 * q) * TILE] = roll ? Xn[q] : (t + 1 < T1 ? nxt.xp[q] : xlast[q]);
+                Xt[(size_t)((t + 1) * NX + g + 4 * q) * TILE] = roll ? Xn[q] : nxt.xp[q];
             }
         }
     }
