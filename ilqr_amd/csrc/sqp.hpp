@@ -363,8 +363,9 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                     const T s = sv[j], lam = lv[j];
                     const T rp = rows.value(j, xq, uq) + s - rows.bnd[j];
                     const T rc = s * lam - sigma * mu;
-                    const T coef = lam + (lam * rp - rc) / s;
-                    const T d = lam / s;
+                    const T inv_s = fast_rcp(s); // (one reciprocal per row instead of two divisions: 6 instructions against 24)
+                    const T coef = lam + (lam * rp - rc) * inv_s;
+                    const T d = lam * inv_s;
                     if (j == 0) {
                         Hx[0][0] += d * rows.gx[0] * rows.gx[0];
                         Hx[0][1] += d * rows.gx[0] * rows.gx[1];
@@ -495,7 +496,10 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
             pending = false;
         }
         // ---- forward sweep: direction, step lengths, and what the step will leave behind
-        T amax = T(1), dmax = T(1), rpabs = T(0), dumax = T(0);
+        // the largest steps that keep slacks and multipliers positive, min over the rows of s / -ds and
+        // lam / -dl, each kept as a fraction (numerator, denominator) and compared by cross-multiplication:
+        // one division per sweep instead of two per row and time step
+        T an = T(1), ad = T(1), dn = T(1), dd = T(1), rpabs = T(0), dumax = T(0);
         T g0 = T(0), g1 = T(0), g2 = T(0), g3 = T(0); // sums of s lam, ds lam, s dl, ds dl over the live rows
         {
             T dx[NX];
@@ -520,15 +524,15 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
 #pragma unroll
                         for (int q = 0; q < NX; ++q) s += st.K[r][q] * dx[q];
                         du[r] = s;
-                        if (!done) DUp[(size_t)(i * NU + r) * TILE] = s;
+                        // (the direction arrays are scratch between this sweep and the next one's `apply`,
+                        // which a finished lane never runs: every lane stores, no branch around the stores)
+                        DUp[(size_t)(i * NU + r) * TILE] = s;
                         const T m = fabs_(s);
                         dumax = m > dumax ? m : dumax;
                     }
                 }
-                if (!done) {
 #pragma unroll
-                    for (int q = 0; q < NX; ++q) DXp[(size_t)(i * NX + q) * TILE] = dx[q];
-                }
+                for (int q = 0; q < NX; ++q) DXp[(size_t)(i * NX + q) * TILE] = dx[q];
                 Rows rows;
                 rows.setup(p, i, T1, xb, st.cx, st.cy, st.rad, fixed0);
 #pragma unroll
@@ -539,14 +543,16 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                         const T rp = rows.value(j, xq, uq) + s - rows.bnd[j];
                         const T rc = s * lam - sigma * mu;
                         ds = -rp - rows.along(j, dx, du);
-                        dl = (-rc - lam * ds) / s;
-                        if (ds < T(0)) {
-                            const T lim = -s / ds;
-                            amax = lim < amax ? lim : amax;
+                        dl = (-rc - lam * ds) * fast_rcp(s);
+                        {   // s / -ds < an / ad  <=>  s ad < an (-ds)   (all four positive)
+                            const bool lower = ds < T(0) && s * ad < an * -ds;
+                            an = lower ? s : an;
+                            ad = lower ? -ds : ad;
                         }
-                        if (dl < T(0)) {
-                            const T lim = -lam / dl;
-                            dmax = lim < dmax ? lim : dmax;
+                        {
+                            const bool lower = dl < T(0) && lam * dd < dn * -dl;
+                            dn = lower ? lam : dn;
+                            dd = lower ? -dl : dd;
                         }
                         g0 += s * lam;
                         g1 += ds * lam;
@@ -555,10 +561,8 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                         const T r1 = fabs_(rp);
                         rpabs = r1 > rpabs ? r1 : rpabs;
                     }
-                    if (!done) {
-                        DSp[(size_t)(i * NR + j) * TILE] = ds;
-                        DLp[(size_t)(i * NR + j) * TILE] = dl;
-                    }
+                    DSp[(size_t)(i * NR + j) * TILE] = ds;
+                    DLp[(size_t)(i * NR + j) * TILE] = dl;
                 }
                 if (i < T1) {
                     T A[NX][NX], Bm[NX][NU], c[NX];
@@ -582,6 +586,7 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
         }
         if (!done) {
             // separate step lengths: alpha for inputs, states and slacks, alphad for the multipliers
+            const T amax = an / ad, dmax = dn / dd;
             const T am = T(0.995) * amax, dm = T(0.995) * dmax;
             alpha = am < T(1) ? am : T(1);
             alphad = dm < T(1) ? dm : T(1);
