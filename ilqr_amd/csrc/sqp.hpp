@@ -44,8 +44,8 @@ template <typename T, class M> struct SqpRows {
         const T ex = xb[0] - cx, ey = xb[1] - cy;
         gx[0] = T(2) * ex;
         gx[1] = T(2) * ey;
-        const T h = ex * ex + ey * ey - rad * rad;                  // constraints.py:20-22
-        bnd[0] = gx[0] * xb[0] + gx[1] * xb[1] - h;                  // constraints.py:28-30
+        const T h = fma_(ex, ex, fma_(ey, ey, -(rad * rad)));       // constraints.py:20-22
+        bnd[0] = fma_(gx[0], xb[0], fma_(gx[1], xb[1], -h));        // constraints.py:28-30
         bnd[1] = -p.vlo;
         bnd[2] = p.vhi;
         const bool st = i >= 1; // the rows of step 0 only test the given initial state
@@ -62,7 +62,7 @@ template <typename T, class M> struct SqpRows {
         }
     }
     __device__ __forceinline__ T value(int j, const T (&x)[NX], const T (&u)[NU]) const {
-        if (j == 0) return gx[0] * x[0] + gx[1] * x[1];
+        if (j == 0) return fma_(gx[0], x[0], gx[1] * x[1]);
         if (j == 1) return -x[2];
         if (j == 2) return x[2];
         const int c = (j - 3) >> 1;
@@ -92,10 +92,10 @@ __device__ __forceinline__ void sqp_linearise(const P &p, int i, const T (&xb)[M
         T s = xbn[a];
 #pragma unroll
         for (int b = 0; b < NX; ++b)
-            if (M::fx_nz(a, b)) s -= M::fx_one(a, b) ? xb[b] : A[a][b] * xb[b];
+            if (M::fx_nz(a, b)) s = M::fx_one(a, b) ? s - xb[b] : fma_(-(A[a][b]), xb[b], s);
 #pragma unroll
         for (int b = 0; b < NU; ++b)
-            if (M::fu_nz(a, b)) s -= B[a][b] * ub[b];
+            if (M::fu_nz(a, b)) s = fma_(-(B[a][b]), ub[b], s);
         c[a] = s;
     }
 }
@@ -249,10 +249,10 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                     T s = c[r];
 #pragma unroll
                     for (int q = 0; q < NX; ++q)
-                        if (M::fx_nz(r, q)) s += M::fx_one(r, q) ? x[q] : A[r][q] * x[q];
+                        if (M::fx_nz(r, q)) s = M::fx_one(r, q) ? s + x[q] : fma_(A[r][q], x[q], s);
 #pragma unroll
                     for (int q = 0; q < NU; ++q)
-                        if (M::fu_nz(r, q)) s += Bm[r][q] * u[q];
+                        if (M::fu_nz(r, q)) s = fma_(Bm[r][q], u[q], s);
                     xn[r] = s;
                 }
 #pragma unroll
@@ -276,20 +276,20 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
     auto apply = [&](int i, const Step &st, const Delta &dv, T (&sv)[NR], T (&lv)[NR], T (&xq)[NX], T (&uq)[NU]) {
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-            sv[j] = st.s[j] + alpha * dv.ds[j];
-            lv[j] = st.lam[j] + alphad * dv.dl[j];
+            sv[j] = fma_(alpha, dv.ds[j], st.s[j]);
+            lv[j] = fma_(alphad, dv.dl[j], st.lam[j]);
             Sp[(size_t)(i * NR + j) * TILE] = sv[j];
             Lp[(size_t)(i * NR + j) * TILE] = lv[j];
         }
 #pragma unroll
         for (int q = 0; q < NX; ++q) {
-            xq[q] = st.xq[q] + alpha * dv.dx[q];
+            xq[q] = fma_(alpha, dv.dx[q], st.xq[q]);
             XQp[(size_t)(i * NX + q) * TILE] = xq[q];
         }
         if (i < T1) {
 #pragma unroll
             for (int q = 0; q < NU; ++q) {
-                uq[q] = st.uq[q] + alpha * dv.du[q];
+                uq[q] = fma_(alpha, dv.du[q], st.uq[q]);
                 UQp[(size_t)(i * NU + q) * TILE] = uq[q];
             }
         }
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
 #pragma unroll
                     for (int q = 0; q < NX; ++q) {
                         Hx[r][q] = W[r * NX + q];
-                        s += W[r * NX + q] * (xq[q] - xr[q]);
+                        s = fma_(W[r * NX + q], (xq[q] - xr[q]), s);
                     }
                     gxv[r] = s;
                 }
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
 #pragma unroll
                     for (int q = 0; q < NU; ++q) {
                         Hu[r][q] = p.R[r * NU + q];
-                        s += p.R[r * NU + q] * uq[q];
+                        s = fma_(p.R[r * NU + q], uq[q], s);
                     }
                     guv[r] = s;
                 }
@@ -367,12 +367,12 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                     const T coef = lam + (lam * rp - rc) * inv_s;
                     const T d = lam * inv_s;
                     if (j == 0) {
-                        Hx[0][0] += d * rows.gx[0] * rows.gx[0];
-                        Hx[0][1] += d * rows.gx[0] * rows.gx[1];
-                        Hx[1][0] += d * rows.gx[1] * rows.gx[0];
-                        Hx[1][1] += d * rows.gx[1] * rows.gx[1];
-                        gxv[0] += coef * rows.gx[0];
-                        gxv[1] += coef * rows.gx[1];
+                        Hx[0][0] = fma_(d * rows.gx[0], rows.gx[0], Hx[0][0]);
+                        Hx[0][1] = fma_(d * rows.gx[0], rows.gx[1], Hx[0][1]);
+                        Hx[1][0] = fma_(d * rows.gx[1], rows.gx[0], Hx[1][0]);
+                        Hx[1][1] = fma_(d * rows.gx[1], rows.gx[1], Hx[1][1]);
+                        gxv[0] = fma_(coef, rows.gx[0], gxv[0]);
+                        gxv[1] = fma_(coef, rows.gx[1], gxv[1]);
                     } else if (j < 3) {
                         Hx[2][2] += d;
                         gxv[2] += j == 1 ? -coef : coef;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                             T s = T(0);
 #pragma unroll
                             for (int w = 0; w < NX; ++w)
-                                if (M::fx_nz(w, q)) s += M::fx_one(w, q) ? Pm[r][w] : Pm[r][w] * A[w][q];
+                                if (M::fx_nz(w, q)) s = M::fx_one(w, q) ? s + Pm[r][w] : fma_(Pm[r][w], A[w][q], s);
                             PA[r][q] = s;
                         }
 #pragma unroll
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                             T s = T(0);
 #pragma unroll
                             for (int w = 0; w < NX; ++w)
-                                if (M::fu_nz(w, q)) s += Pm[r][w] * Bm[w][q];
+                                if (M::fu_nz(w, q)) s = fma_(Pm[r][w], Bm[w][q], s);
                             PB[r][q] = s;
                         }
                     }
@@ -417,14 +417,14 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                         T s = gxv[r];
 #pragma unroll
                         for (int w = 0; w < NX; ++w)
-                            if (M::fx_nz(w, r)) s += M::fx_one(w, r) ? pv[w] : A[w][r] * pv[w];
+                            if (M::fx_nz(w, r)) s = M::fx_one(w, r) ? s + pv[w] : fma_(A[w][r], pv[w], s);
                         Qx[r] = s;
 #pragma unroll
                         for (int q = 0; q < NX; ++q) {
                             T t = Hx[r][q];
 #pragma unroll
                             for (int w = 0; w < NX; ++w)
-                                if (M::fx_nz(w, r)) t += M::fx_one(w, r) ? PA[w][q] : A[w][r] * PA[w][q];
+                                if (M::fx_nz(w, r)) t = M::fx_one(w, r) ? t + PA[w][q] : fma_(A[w][r], PA[w][q], t);
                             Qxx[r][q] = t;
                         }
                     }
@@ -433,14 +433,14 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                         T s = guv[r];
 #pragma unroll
                         for (int w = 0; w < NX; ++w)
-                            if (M::fu_nz(w, r)) s += Bm[w][r] * pv[w];
+                            if (M::fu_nz(w, r)) s = fma_(Bm[w][r], pv[w], s);
                         Qu[r] = s;
 #pragma unroll
                         for (int q = 0; q < NX; ++q) {
                             T t = T(0);
 #pragma unroll
                             for (int w = 0; w < NX; ++w)
-                                if (M::fu_nz(w, r)) t += Bm[w][r] * PA[w][q];
+                                if (M::fu_nz(w, r)) t = fma_(Bm[w][r], PA[w][q], t);
                             Qux[r][q] = t;
                         }
 #pragma unroll
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                             T t = Hu[r][q];
 #pragma unroll
                             for (int w = 0; w < NX; ++w)
-                                if (M::fu_nz(w, r)) t += Bm[w][r] * PB[w][q];
+                                if (M::fu_nz(w, r)) t = fma_(Bm[w][r], PB[w][q], t);
                             Quu[r][q] = t;
                         }
                     }
@@ -478,13 +478,13 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                     for (int r = 0; r < NX; ++r) {
                         T s = Qx[r];
 #pragma unroll
-                        for (int w = 0; w < NU; ++w) s += rhs[w][r] * Qu[w];
+                        for (int w = 0; w < NU; ++w) s = fma_(rhs[w][r], Qu[w], s);
                         pv[r] = s;
 #pragma unroll
                         for (int q = 0; q < NX; ++q) {
                             T t = Qxx[r][q];
 #pragma unroll
-                            for (int w = 0; w < NU; ++w) t += rhs[w][r] * Qux[w][q];
+                            for (int w = 0; w < NU; ++w) t = fma_(rhs[w][r], Qux[w][q], t);
                             Pm[r][q] = t;
                         }
                     }
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                     for (int r = 0; r < NU; ++r) {
                         T s = st.k[r];
 #pragma unroll
-                        for (int q = 0; q < NX; ++q) s += st.K[r][q] * dx[q];
+                        for (int q = 0; q < NX; ++q) s = fma_(st.K[r][q], dx[q], s);
                         du[r] = s;
                         // (the direction arrays are scratch between this sweep and the next one's `apply`,
                         // which a finished lane never runs: every lane stores, no branch around the stores)
@@ -554,10 +554,10 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                             dn = lower ? lam : dn;
                             dd = lower ? -dl : dd;
                         }
-                        g0 += s * lam;
-                        g1 += ds * lam;
-                        g2 += s * dl;
-                        g3 += ds * dl;
+                        g0 = fma_(s, lam, g0);
+                        g1 = fma_(ds, lam, g1);
+                        g2 = fma_(s, dl, g2);
+                        g3 = fma_(ds, dl, g3);
                         const T r1 = fabs_(rp);
                         rpabs = r1 > rpabs ? r1 : rpabs;
                     }
@@ -573,10 +573,10 @@ __global__ __launch_bounds__(64) void sqp_qp_kernel(Params<T, M::NX, M::NU> p, S
                         T s = T(0);
 #pragma unroll
                         for (int q = 0; q < NX; ++q)
-                            if (M::fx_nz(r, q)) s += M::fx_one(r, q) ? dx[q] : A[r][q] * dx[q];
+                            if (M::fx_nz(r, q)) s = M::fx_one(r, q) ? s + dx[q] : fma_(A[r][q], dx[q], s);
 #pragma unroll
                         for (int q = 0; q < NU; ++q)
-                            if (M::fu_nz(r, q)) s += Bm[r][q] * du[q];
+                            if (M::fu_nz(r, q)) s = fma_(Bm[r][q], du[q], s);
                         dxn[r] = s;
                     }
 #pragma unroll
