@@ -289,13 +289,21 @@ static int unpack(ilqr_handle *h, PartState &ps, hipStream_t s) {
     if (!ps.packed) return ILQR_OK; // everything is in the caller's buffers already
     int rc = repack(h, ps, REPACK_RETIRE_ALL, s);
     if (rc != ILQR_OK) return rc;
-    // gains of the converged problems: one backward pass over them in the caller's buffers (it
-    // also writes gains for their tile neighbours that never converged; the next step replaces those)
+    // gains of the converged problems: one backward pass over them in the caller's buffers.  Every lane
+    // of a tile stores, so the pass also writes gains for their tile neighbours that never converged:
+    // where the kernels can, it passes those on from the working set (HostCtx::gather_K), else a
+    // retirement launch replaces them afterwards.
     HostCtx c = ps.ctx;
+    const bool gather = h->ops->gathers != 0 && (h->ctx.d.constraint_mode & 3) == 0;
+    if (gather) {
+        c.gather_K = ps.ctx.ws.K;
+        c.gather_k = ps.ctx.ws.k;
+        c.gather_slot = (const int32_t *)((char *)ps.ctx.b.work + work_layout(h->ctx.d, true).orig2slot);
+    }
     c.ws = HostCtx::WorkSet();
     c.select_converged = true;
     rc = hip_rc(h->ops->backward(c, 0, s));
-    if (rc != ILQR_OK) return rc;
+    if (rc != ILQR_OK || gather) return rc;
     return repack(h, ps, REPACK_RETIRE_LIVE, s);
 }
 

@@ -25,6 +25,10 @@ struct HostCtx {
     // roll the previous states out again instead of reading them
     bool reroll = false;
     bool select_converged = false; // backward pass: recompute the gains of the converged problems
+    // ... and, in the same pass, pass on the gains of the problems that never converged from the last
+    // working set (tiled by slot; gather_slot[global problem index] = slot); null = off (Params::gK)
+    const void *gather_K = nullptr, *gather_k = nullptr;
+    const int32_t *gather_slot = nullptr;
     // the commits keep the sine/cosine pairs of the committed trajectory in `work` (Params::SC) and,
     // while `reroll` holds, the backward pass and the line search read them instead of evaluating
     bool trig = false;
@@ -123,6 +127,8 @@ struct ModelOps {
     launch_fn solve;
     // fills in the state rows sparse commits left out (states_kernel); null if the model has no sparse variant
     launch_fn states;
+    // the unconstrained backward pass honours HostCtx::gather_K (else the caller retires those gains itself)
+    int gathers;
 };
 
 // What a separately compiled model library (ilqr_load_model) hands to this one.  `abi` must equal
@@ -137,7 +143,7 @@ struct PluginInfo {
     const ModelOps *(*ops)(int dtype, bool diag);
     const SqpOps *(*sqp)(int dtype); // sequential-QP kernels for this model, or a function returning null
 };
-constexpr int32_t PLUGIN_ABI_VERSION = 7;
+constexpr int32_t PLUGIN_ABI_VERSION = 8;
 static inline int32_t plugin_abi() {
     return (int32_t)(PLUGIN_ABI_VERSION * 1000003u + sizeof(HostCtx) * 31u + sizeof(ilqr_desc) * 7u + sizeof(ilqr_buffers));
 }
@@ -212,6 +218,9 @@ template <typename T, int NX, int NU> static Params<T, NX, NU> make_params(const
     // (indexed like the other per-problem arrays: by global problem index through the slot map, by
     // the index within the part otherwise)
     p.carried = c.select_converged ? flat((const int32_t *)((char *)b.work + work_layout(d, true).carried)) : nullptr;
+    p.gK = (const T *)c.gather_K;
+    p.gk = (const T *)c.gather_k;
+    p.gslot = flat(c.gather_slot);
     p.slots_lo = -1;
     p.slots_hi = 0x7fffffff;
     p.dt = (T)d.dt;
@@ -303,6 +312,12 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
         if constexpr (HAS_TRIG) {
             if (use_trig(c)) {
                 hipLaunchKernelGGL((backward_kernel<T, M, DIAG, CONSTR, PF_BACKWARD, true>), dim3((c.count + 63) / 64), dim3(64), 0, s, p);
+                return hipGetLastError();
+            }
+        }
+        if constexpr (LAZY_BUILT && CONSTR == 0) {
+            if (c.select_converged && c.gather_slot != nullptr) {
+                hipLaunchKernelGGL((backward_kernel<T, M, DIAG, 0, PF_BACKWARD, false, true>), dim3((c.count + 63) / 64), dim3(64), 0, s, p);
                 return hipGetLastError();
             }
         }
@@ -606,7 +621,7 @@ template <typename T, template <typename> class MT, bool DIAG> struct Launch {
     }
     static const ModelOps *table() {
         static const ModelOps ops = {&cost, &backward, &evaluate, &commit, &probe, &rollout, trig_pairs<M>::value, &solve,
-                                     LAZY_BUILT ? &states : nullptr};
+                                     LAZY_BUILT ? &states : nullptr, LAZY_BUILT ? 1 : 0};
         return &ops;
     }
 };

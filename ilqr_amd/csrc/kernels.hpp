@@ -152,6 +152,11 @@ template <typename T, int NX, int NU> struct Params {
     int32_t *list;
     int32_t *list_count;
     const int32_t *carried; // per problem: was ever copied into a working set (select_converged only)
+    // backward pass over the caller's buffers at the end of a compacted solve (select_converged): the
+    // gains of the problems that never converged rest in the last working set (gK, gk, tiled by slot;
+    // gslot[problem] = slot) and are copied into the rows this pass stores anyway.  Null = off.
+    const T *gK, *gk;
+    const int32_t *gslot;
     int32_t *redo; // per problem: the backward pass must be repeated with the pivoted-LU solve (n = 12 model)
     T *trash; // 64 values per tile: where lanes that must not change their trajectory store (commit, REROLL)
     // Sine/cosine cache (null = off): tiled, rows = (N-1) * 2 (sine, cosine of the model's shared angle
@@ -786,8 +791,9 @@ __device__ __forceinline__ int riccati_step(const P &p, int t, const T (&x)[M::N
     return st;
 }
 
-template <typename T, int NX, int NU> struct StepRow { // the rows of one time step the backward pass reads
+template <typename T, int NX, int NU, bool G = false> struct StepRow { // the rows of one time step the backward pass reads
     T x[NX], u[NU], xr[NX], cx, cy, rad, s, c;
+    T gK[G ? NU : 1][G ? NX : 1], gk[G ? NU : 1]; // G: gains to be passed on instead of the computed ones (see Params::gK)
 };
 
 // One reverse sweep over the horizon for the problem of this lane; returns status bits and
@@ -797,12 +803,23 @@ template <typename T, int NX, int NU> struct StepRow { // the rows of one time s
 // TC: sine/cosine pairs are read from SCp (Params::SC) and `store` also guards the fast sweep (the
 // lanes of converged problems may hold no valid pairs, so they must not rewrite their gains).
 // COND: also the fast sweep stores only for the lanes with `store`.
-template <typename T, class M, bool DIAG, int CONSTR, int PF, bool FAST, bool TC = false, bool COND = false, class P>
+// GATHER: the lanes with `take` store the gains found at Kg, kg (a problem's rows in another tiling) instead
+// of the ones they compute; the other lanes' Kg, kg point at any valid rows.
+template <typename T, class M, bool DIAG, int CONSTR, int PF, bool FAST, bool TC = false, bool COND = false, bool GATHER = false, class P>
 __device__ __forceinline__ int backward_sweep(const P &p, const T *Xt, const T *Rt, const T *Ut, const T *Cp, const T *Dp,
-                                              T *Kp, T *kp, bool &bad, bool store = true, const T *SCp = nullptr) {
+                                              T *Kp, T *kp, bool &bad, bool store = true, const T *SCp = nullptr,
+                                              const T *Kg = nullptr, const T *kg = nullptr, bool take = false) {
     constexpr int NX = M::NX, NU = M::NU;
     const int T1 = p.N - 1;
-    auto load_row = [&](int t, StepRow<T, NX, NU> &r) {
+    auto load_row = [&](int t, StepRow<T, NX, NU, GATHER> &r) {
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                r.gk[i] = kg[gain_k<M>(t, i)];
+#pragma unroll
+                for (int j = 0; j < NX; ++j) r.gK[i][j] = Kg[gain_K<M>(t * NU + i, j)];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             r.x[i] = Xt[(t * NX + i) * TILE];
@@ -851,7 +868,7 @@ __device__ __forceinline__ int backward_sweep(const P &p, const T *Xt, const T *
             barrier_terms<T, NX, true>(p, x, Cp[(T1 * 2 + 0) * TILE], Cp[(T1 * 2 + 1) * TILE], Dp[T1 * TILE], Vx, Vxx);
     }
 
-    StepRow<T, NX, NU> ring[PF];
+    StepRow<T, NX, NU, GATHER> ring[PF];
 #pragma unroll
     for (int s = 0; s < PF; ++s)
         if (T1 - 1 - s >= 0) load_row(T1 - 1 - s, ring[s]);
@@ -861,7 +878,7 @@ __device__ __forceinline__ int backward_sweep(const P &p, const T *Xt, const T *
         for (int s = 0; s < PF; ++s) {
             const int t = tb - s;
             if (t < 0) break;
-            StepRow<T, NX, NU> cur = ring[s];
+            StepRow<T, NX, NU, GATHER> cur = ring[s];
             if (t - PF >= 0) load_row(t - PF, ring[s]);
             T Kt[NU][NX], kt[NU];
             status |= riccati_step<T, M, DIAG, CONSTR, FAST, TC>(p, t, cur.x, cur.u, cur.xr, cur.cx, cur.cy, cur.rad, Vx, Vxx, Kt, kt, bad,
@@ -873,9 +890,15 @@ __device__ __forceinline__ int backward_sweep(const P &p, const T *Xt, const T *
             if ((FAST && !TC && !COND) || store) {
 #pragma unroll
                 for (int i = 0; i < NU; ++i) {
-                    kp[gain_k<M>(t, i)] = kt[i];
+                    if constexpr (GATHER) {
+                        kp[gain_k<M>(t, i)] = take ? cur.gk[i] : kt[i];
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) Kp[gain_K<M>(t * NU + i, j)] = Kt[i][j];
+                        for (int j = 0; j < NX; ++j) Kp[gain_K<M>(t * NU + i, j)] = take ? cur.gK[i][j] : Kt[i][j];
+                    } else {
+                        kp[gain_k<M>(t, i)] = kt[i];
+#pragma unroll
+                        for (int j = 0; j < NX; ++j) Kp[gain_K<M>(t * NU + i, j)] = Kt[i][j];
+                    }
                 }
             }
         }
@@ -884,7 +907,7 @@ __device__ __forceinline__ int backward_sweep(const P &p, const T *Xt, const T *
 }
 
 // The backward pass of the problem in slot b0 (one lane per problem).
-template <typename T, class M, bool DIAG, int CONSTR, int PF, bool TC = false, class P>
+template <typename T, class M, bool DIAG, int CONSTR, int PF, bool TC = false, bool GATHER = false, class P>
 __device__ __forceinline__ void backward_body(const P &p, int b0) {
     constexpr int NX = M::NX, NU = M::NU;
     const int nsl = slot_count(p);
@@ -894,7 +917,9 @@ __device__ __forceinline__ void backward_body(const P &p, int b0) {
     // normally the problems still iterating; at the end of a solve with compaction, the converged ones
     // whose gains were computed inside a working set
     const bool active = valid && (p.select_converged ? (p.converged[o] != 0 && p.carried[o] != 0) : p.converged[o] == 0);
-    if (__ballot(active) == 0ull) return;
+    // (GATHER: the problems that never converged: every one of them is in the last working set)
+    const bool take = GATHER && valid && p.converged[o] == 0;
+    if (__ballot(active || take) == 0ull) return;
     const int T1 = p.N - 1;
     constexpr bool BARRIER_ = (CONSTR & 2) != 0;
     const int tile = b0 >> 6, ln = b0 & 63; // buffers are padded to whole tiles
@@ -907,6 +932,21 @@ __device__ __forceinline__ void backward_body(const P &p, int b0) {
     T *Kp = tile_ptr_v<GainLayout<M>::VK>(p.K, tile, T1 * NU * NX, ln);
     const T *SCp = TC ? tile_ptr(p.SC, tile, T1 * 2, ln) : nullptr;
     bool bad = false;
+    if constexpr (GATHER) {
+        const int gs = take ? p.gslot[o] : 0;
+        const T *kg = tile_ptr_v<GainLayout<M>::Vk>(p.gk, gs >> 6, T1 * NU, gs & 63);
+        const T *Kg = tile_ptr_v<GainLayout<M>::VK>(p.gK, gs >> 6, T1 * NU * NX, gs & 63);
+        int status = backward_sweep<T, M, DIAG, CONSTR, PF, true, false, false, true>(p, Xt, Rt, Ut, Cp, Dp, Kp, kp, bad, true, nullptr, Kg, kg, take);
+        // (the lanes that pass gains on computed theirs for nothing: whatever their sweep met does not count)
+        const bool redo = bad && valid && !take;
+        if (__ballot(redo) != 0ull) {
+            bool bad2 = false;
+            const int status2 = backward_sweep<T, M, DIAG, CONSTR, 1, false, false>(p, Xt, Rt, Ut, Cp, Dp, Kp, kp, bad2, redo, nullptr);
+            status = redo ? status2 : status;
+        }
+        if (active && status != 0 && p.status) p.status[o] |= status;
+        return;
+    }
     int status = backward_sweep<T, M, DIAG, CONSTR, PF, true, TC>(p, Xt, Rt, Ut, Cp, Dp, Kp, kp, bad, active, SCp);
     // rare: an angle outside the fast trigonometric range or a Quu that is not positive definite
     // somewhere in the wave: the lanes that raised the flag redo their sweep with the library
@@ -922,9 +962,9 @@ __device__ __forceinline__ void backward_body(const P &p, int b0) {
     if (active && status != 0 && p.status) p.status[o] |= status;
 }
 
-template <typename T, class M, bool DIAG, int CONSTR, int PF, bool TC = false>
+template <typename T, class M, bool DIAG, int CONSTR, int PF, bool TC = false, bool GATHER = false>
 __global__ __launch_bounds__(64) void backward_kernel(Params<T, M::NX, M::NU> p) {
-    backward_body<T, M, DIAG, CONSTR, PF, TC>(p, blockIdx.x * 64 + threadIdx.x);
+    backward_body<T, M, DIAG, CONSTR, PF, TC, GATHER>(p, blockIdx.x * 64 + threadIdx.x);
 }
 
 // The reverse sweep for a problem of whose states only the rows 0, XCK, 2 XCK .. are stored
