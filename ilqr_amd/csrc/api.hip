@@ -198,10 +198,12 @@ static hipError_t repack_launch(ilqr_handle *h, PartState &ps, int mode, hipStre
     a.orig2slot = (int32_t *)(work + wl.orig2slot);
     const bool pk = ps.packed;
     a.first_repack = pk ? 0 : 1;
+    a.slow_trig = (const int32_t *)(work + wl.slow);
     a.gen_prev = 0;
     int chunks = 0;
     auto add = [&](const void *src, T *dst_active, T *dst_retire, int rows, int vec = 1) {
         a.arr[a.narr].vshift = vec == 4 ? 2 : vec == 2 ? 1 : 0;
+        a.arr[a.narr].sparse_nx = 0;
         a.arr[a.narr].src_prev = nullptr;
         a.arr[a.narr].src = (const T *)src;
         a.arr[a.narr].dst_active = dst_active;
@@ -245,6 +247,8 @@ static hipError_t repack_launch(ilqr_handle *h, PartState &ps, int mode, hipStre
         chunks = 0;
         a.gen = ps.gen + 1;
         add(Xc, set_ptr(q, 0, N * n), nullptr, N * n);
+        // (with sparse states the problems whose trajectory regenerates from its stored rows take only those along)
+        if (ps.ctx.lazy) a.arr[a.narr - 1].sparse_nx = n;
         add(Uc, set_ptr(q, 1, T1 * m), nullptr, T1 * m);
         add(Rc, set_ptr(q, 2, N * n), nullptr, N * n, barrier ? 1 : gain_vec_of(n, n)); // (TargetLayout)
         if (barrier) {
@@ -267,6 +271,7 @@ static hipError_t repack_launch(ilqr_handle *h, PartState &ps, int mode, hipStre
     ps.ctx.ws.nslots = nslots_new;
     ps.packed = true;
     ps.parity = q;
+    if (ps.ctx.lazy) ps.stale = true; // (the new working set holds the stored rows only, as after a sparse commit)
     return hipSuccess;
 }
 

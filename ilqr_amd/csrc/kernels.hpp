@@ -3516,6 +3516,10 @@ template <typename T> struct RepackArray {
     int rows;       // values per problem
     int chunk0;     // first chunk (REPACK_CHUNK rows each) of this array in the grid's y range
     int vshift;     // log2 of the rows interleaved per problem (GainLayout; 0: plain tiled layout)
+    // repack_move_kernel, states only: > 0 = the state size; of a tile whose active problems are all marked
+    // as regenerable (SLOW_TRIG_REGEN) only the rows of the time steps 0, XCK, 2 XCK .. move on (the
+    // destination is then as sparse as a sparse commit leaves it)
+    int sparse_nx;
 };
 // offset of row i of lane `lane` from the start of a tile, V = 1 << vshift rows interleaved
 __device__ __forceinline__ size_t tile_elem(int i, int lane, int vshift) {
@@ -3547,6 +3551,7 @@ template <typename T> struct RepackArgs {
     // is only read out when the next but one is about to be built over it, or at the end of the solve
     int gen_prev;
     int first_repack;             // the current arrays are the caller's buffers: define `carried` for every problem
+    const int32_t *slow_trig;     // per problem, global index (RepackArray::sparse_nx); may be null
 };
 
 // Source-major half of a repack: the active problems of the current working set go, in order, into
@@ -3577,16 +3582,19 @@ template <typename T> __global__ __launch_bounds__(64) void repack_move_kernel(R
     const int i0 = ((int)blockIdx.y - r.chunk0) * REPACK_CHUNK;
     T *dst = act ? r.dst_active + (size_t)(ns >> 6) * r.rows * TILE : nullptr;
     const T *src = r.src + (size_t)tile * r.rows * TILE;
+    // states of regenerable problems: only the stored rows (uniform over the wave)
+    bool sparse = false;
+    if (r.sparse_nx > 0 && a.slow_trig) sparse = __ballot(act && (a.slow_trig[o] & SLOW_TRIG_REGEN) == 0) == 0ull;
     T v[REPACK_CHUNK];
 #pragma unroll
     for (int j = 0; j < REPACK_CHUNK; ++j) {
-        const int i = i0 + j < r.rows ? i0 + j : r.rows - 1; // no branch around the loads
-        v[j] = src[tile_elem(i, lane, r.vshift)];
+        const int i = i0 + j < r.rows ? i0 + j : r.rows - 1; // no branch around the loads but a uniform one
+        if (!sparse || (i / r.sparse_nx) % XCK == 0) v[j] = src[tile_elem(i, lane, r.vshift)];
     }
     if (dst) {
 #pragma unroll
         for (int j = 0; j < REPACK_CHUNK; ++j)
-            if (i0 + j < r.rows) dst[tile_elem(i0 + j, ns & 63, r.vshift)] = v[j];
+            if (i0 + j < r.rows && (!sparse || ((i0 + j) / r.sparse_nx) % XCK == 0)) dst[tile_elem(i0 + j, ns & 63, r.vshift)] = v[j];
     }
 }
 
